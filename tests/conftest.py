@@ -1,0 +1,24 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    z = np.load(os.path.join(HERE, "golden", "vtm_golden.npz"), allow_pickle=False)
+    data = {k: z[k] for k in z.files}
+    data["manifest"] = json.loads(bytes(data.pop("manifest_json")).decode())
+    return data

@@ -1,0 +1,78 @@
+"""The parity fixture list shared by tests/golden/make_golden.py (which runs the REAL
+reference, oracle/_ref/ref_vtm, in the build container) and by the tests that replay
+the fixtures (oracle on CPU, HIP path on the GPU).
+
+Each case: name, track recipe, model string for ref_vtm, SectionDelay for our side,
+output rate, control rate, config overrides (on top of tests/golden/voice_male.txt),
+and how much of the reference output is stored ("full" or "digest").
+"""
+import numpy as np
+
+import tracks
+
+
+def _track(spec, golden=None):
+    kind = spec[0]
+    if kind == "const":
+        return tracks.const_track(spec[1])
+    if kind == "ramp":
+        return tracks.ramp_track(spec[1])
+    if kind == "random":
+        t = tracks.random_track(spec[1], spec[2], spec[3])
+        return t[: spec[4]] if len(spec) > 4 else t
+    if kind == "hello":
+        return np.asarray(golden["hello_params"], dtype=np.float32)
+    if kind == "silence":
+        t = tracks.const_track(spec[1])
+        t[:, 1:4] = 0.0
+        return t
+    raise ValueError(kind)
+
+
+def track_for(case, golden=None):
+    return _track(case["track"], golden)
+
+
+def C(name, track, model="0", delay=1, rate=44100.0, crate=250.0, store="full", **ov):
+    return dict(name=name, track=track, model=model, delay=delay, rate=rate, crate=crate, store=store, overrides=ov)
+
+
+CASES = [
+    # SURVEY.md section 0 known-answer tracks (500 frames -> 88108 samples): digest + strided subset
+    C("const_m0", ("const", 500), store="digest"),
+    C("ramp_m0", ("ramp", 500), store="digest"),
+    C("const_m2d2", ("const", 500), model="2:2", delay=2, store="digest"),
+    C("ramp_m2d2", ("ramp", 500), model="2:2", delay=2, store="digest"),
+    C("const_m3", ("const", 500), model="3", delay=3, store="digest"),
+    C("ramp_m3", ("ramp", 500), model="3", delay=3, store="digest"),
+    C("rand1000_m0", ("random", 500, 1000, False), store="digest"),
+    C("cons2000_m2", ("random", 500, 2000, True), model="2", store="digest"),
+    # the real text->posture track of BASELINE.json configs[0]
+    C("hello_m0", ("hello",), store="full"),
+    C("hello_m0_48k", ("hello",), rate=48000.0, store="digest"),
+    # short tracks, full output stored
+    C("rand5_m0", ("random", 120, 5, True)),
+    C("rand5_m2d2", ("random", 120, 5, True), model="2:2", delay=2),
+    C("rand5_m3", ("random", 120, 5, True), model="3", delay=3),
+    C("tn_delta", ("random", 120, 5, True), glottal_pulse_tn_min=16.0, glottal_pulse_tn_max=32.0),
+    C("tn_delta_d2", ("random", 120, 5, True), model="2:2", delay=2, glottal_pulse_tn_min=10.0, glottal_pulse_tn_max=40.0),
+    C("sine", ("random", 120, 5, True), waveform=1),
+    C("no_modulation", ("random", 120, 5, True), noise_modulation=0),
+    C("out48k", ("random", 120, 5, True), rate=48000.0),
+    C("out22k", ("random", 120, 5, True), rate=22050.0),
+    C("out16k_down", ("random", 120, 5, True), rate=16000.0),
+    C("crate1000", ("random", 120, 5, True), crate=1000.0),
+    C("crate500_m3", ("random", 120, 5, True), model="3", delay=3, crate=500.0),
+    C("female", ("random", 120, 6, False), vocal_tract_length=15.0, glottal_pulse_tn_min=32.0,
+      glottal_pulse_tn_max=32.0, breathiness=1.5),
+    C("small_child", ("random", 120, 7, False), vocal_tract_length=10.0, breathiness=1.5),
+    C("radius_coefs", ("random", 120, 8, True), radius_3_coef=1.3, global_radius_coef=0.9,
+      global_nasal_radius_coef=1.1, vocal_tract_length_offset=1.0),
+    C("silence", ("silence", 40)),
+    C("one_frame", ("random", 120, 5, True, 1)),
+    C("two_frames_m3", ("random", 120, 5, True, 2), model="3", delay=3),
+    C("three_frames", ("random", 120, 5, True, 3)),
+    C("thirteen_frames_m3", ("random", 120, 5, True, 13), model="3", delay=3),
+]
+
+DIGEST_STRIDE = 97

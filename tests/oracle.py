@@ -1,0 +1,207 @@
+"""ctypes binding of the CPU oracle (oracle/vtm_oracle.c) — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libvtm_oracle.so")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+VOICE_MALE = os.path.join(GOLDEN_DIR, "voice_male.txt")
+
+
+class OracleConfig(ctypes.Structure):
+    _fields_ = [
+        ("output_rate", ctypes.c_double),
+        ("waveform", ctypes.c_int),
+        ("glottal_pulse_tp", ctypes.c_double),
+        ("glottal_pulse_tn_min", ctypes.c_double),
+        ("glottal_pulse_tn_max", ctypes.c_double),
+        ("breathiness", ctypes.c_double),
+        ("vocal_tract_length_offset", ctypes.c_double),
+        ("vocal_tract_length", ctypes.c_double),
+        ("temperature", ctypes.c_double),
+        ("loss_factor", ctypes.c_double),
+        ("mouth_coefficient", ctypes.c_double),
+        ("nose_coefficient", ctypes.c_double),
+        ("throat_cutoff", ctypes.c_double),
+        ("throat_volume", ctypes.c_double),
+        ("noise_modulation", ctypes.c_int),
+        ("mix_offset", ctypes.c_double),
+        ("global_radius_coef", ctypes.c_double),
+        ("global_nasal_radius_coef", ctypes.c_double),
+        ("aperture_radius", ctypes.c_double),
+        ("nasal_radius", ctypes.c_double * 5),
+        ("radius_coef", ctypes.c_double * 8),
+        ("section_delay", ctypes.c_int),
+    ]
+
+
+class OracleDerived(ctypes.Structure):
+    _fields_ = [
+        ("sample_rate", ctypes.c_int),
+        ("control_steps", ctypes.c_uint),
+        ("fir_taps", ctypes.c_int),
+        ("table_div1", ctypes.c_uint),
+        ("table_div2", ctypes.c_uint),
+        ("tn_delta", ctypes.c_double),
+        ("time_register_increment", ctypes.c_uint),
+        ("phase_increment", ctypes.c_uint),
+        ("pad_size", ctypes.c_int),
+        ("upsampling", ctypes.c_int),
+    ]
+
+
+def read_config_file(path):
+    """key = value file in the reference's ConfigurationData format (ConfigurationData.cpp:67-118)."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line or line.startswith("#"):
+                continue
+            k, v = line.split("=", 1)
+            out[k.strip()] = v.strip()
+    return out
+
+
+def config_from_dict(d, output_rate=None, section_delay=1):
+    c = OracleConfig()
+    c.output_rate = float(d["output_rate"]) if output_rate is None else float(output_rate)
+    c.waveform = int(float(d["waveform"]))
+    for k in ("glottal_pulse_tp", "glottal_pulse_tn_min", "glottal_pulse_tn_max", "breathiness",
+              "vocal_tract_length_offset", "vocal_tract_length", "temperature", "loss_factor",
+              "mouth_coefficient", "nose_coefficient", "throat_cutoff", "throat_volume", "mix_offset",
+              "global_radius_coef", "global_nasal_radius_coef", "aperture_radius"):
+        setattr(c, k, float(d[k]))
+    c.noise_modulation = int(float(d["noise_modulation"]))
+    for i in range(5):
+        c.nasal_radius[i] = float(d["nasal_radius_%d" % (i + 1)])
+    for i in range(8):
+        c.radius_coef[i] = float(d["radius_%d_coef" % (i + 1)])
+    c.section_delay = section_delay
+    return c
+
+
+def male_config(output_rate=44100.0, section_delay=1, **overrides):
+    d = read_config_file(VOICE_MALE)
+    d.update({k: str(v) for k, v in overrides.items()})
+    return config_from_dict(d, output_rate, section_delay)
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "vtm_oracle.c")
+        if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+            build()
+        L = ctypes.CDLL(LIB_PATH)
+        P = ctypes.POINTER
+        L.vtmo_derive.argtypes = [P(OracleConfig), ctypes.c_double, P(OracleDerived)]
+        L.vtmo_derive.restype = ctypes.c_int
+        L.vtmo_fir_coefficients.argtypes = [ctypes.c_void_p]
+        L.vtmo_fir_coefficients.restype = ctypes.c_int
+        L.vtmo_src_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.vtmo_wavetable.argtypes = [P(OracleConfig), ctypes.c_int, ctypes.c_void_p]
+        L.vtmo_noise_sequence.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.vtmo_output_count.argtypes = [P(OracleConfig), ctypes.c_double, ctypes.c_size_t]
+        L.vtmo_output_count.restype = ctypes.c_size_t
+        L.vtmo_synthesize.argtypes = [P(OracleConfig), ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.vtmo_synthesize.restype = ctypes.c_size_t
+        L.vtmo_synthesize_batch.argtypes = [P(OracleConfig), ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        L.vtmo_synthesize_batch.restype = ctypes.c_size_t
+        L.vtmo_output_scale.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.vtmo_output_scale.restype = ctypes.c_float
+        _lib = L
+    return _lib
+
+
+def derive(cfg, control_rate=250.0):
+    d = OracleDerived()
+    rc = lib().vtmo_derive(ctypes.byref(cfg), control_rate, ctypes.byref(d))
+    if rc != 0:
+        raise ValueError("bad oracle config")
+    return d
+
+
+def output_count(cfg, frames, control_rate=250.0):
+    return lib().vtmo_output_count(ctypes.byref(cfg), control_rate, frames)
+
+
+def synthesize(cfg, params, control_rate=250.0, want_internal=False):
+    """params: float32 [F][16] -> float32 [N] (and the internal-rate float64 signal)."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    assert params.ndim == 2 and params.shape[1] == 16
+    frames = params.shape[0]
+    n = output_count(cfg, frames, control_rate)
+    out = np.empty(n, dtype=np.float32)
+    internal = None
+    ip = None
+    if want_internal:
+        internal = np.empty(frames * derive(cfg, control_rate).control_steps, dtype=np.float64)
+        ip = internal.ctypes.data
+    got = lib().vtmo_synthesize(ctypes.byref(cfg), control_rate, params.ctypes.data, frames,
+                                out.ctypes.data, n, ip)
+    assert got == n, (got, n)
+    return (out, internal) if want_internal else out
+
+
+def synthesize_batch(cfg, params, control_rate=250.0):
+    """params: float32 [B][F][16] -> float32 [B][N]."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    assert params.ndim == 3 and params.shape[2] == 16
+    b, frames = params.shape[:2]
+    n = output_count(cfg, frames, control_rate)
+    out = np.empty((b, n), dtype=np.float32)
+    got = lib().vtmo_synthesize_batch(ctypes.byref(cfg), control_rate, params.ctypes.data, b, frames,
+                                      out.ctypes.data, n)
+    assert got == n, (got, n)
+    return out
+
+
+def output_scale(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return float(lib().vtmo_output_scale(x.ctypes.data, x.size))
+
+
+# --- the real reference, compiled here from /root/reference (oracle/_ref/, see oracle/Makefile) ---
+
+def ref_binary(kind="gold"):
+    name = {"gold": "ref_vtm", "o3": "ref_vtm_o3", "v3": "ref_vtm_v3"}[kind]
+    p = os.path.join(REF_DIR, name)
+    return p if os.path.exists(p) else None
+
+
+def ref_synthesize(params, model="0", output_rate=44100, control_rate=250, config=VOICE_MALE, kind="gold",
+                   repeat=1, tmpdir=None):
+    """Run the compiled reference on float32 frames; returns (audio float32, info dict)."""
+    import tempfile
+    exe = ref_binary(kind)
+    if exe is None:
+        raise FileNotFoundError("oracle/_ref not built")
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    with tempfile.TemporaryDirectory(dir=tmpdir) as td:
+        pin = os.path.join(td, "p.f32")
+        pout = os.path.join(td, "o.f32")
+        params.tofile(pin)
+        r = subprocess.run([exe, config, str(model), repr(float(output_rate)), repr(float(control_rate)), pin,
+                            str(params.shape[0]), pout, str(repeat)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("ref_vtm failed: " + r.stderr)
+        info = dict(kv.split("=") for kv in r.stdout.split())
+        return np.fromfile(pout, dtype=np.float32), info

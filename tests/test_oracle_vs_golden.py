@@ -1,0 +1,96 @@
+"""Pins the CPU oracle: it must reproduce every committed reference vector bit for bit.
+
+The vectors in tests/golden/vtm_golden.npz were produced by the real GamaTTS classes
+(oracle/_ref/ref_vtm, see tests/golden/make_golden.py); the reference itself ships no
+tests for this path, so these are the pins.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import golden_cases
+import oracle
+import tracks
+
+# SURVEY.md section 0 known-answer table (reference built -O2 -ffp-contract=off)
+KAT = {
+    "const_m0": (88108, 7.871065063e+00, 7.537760539e-04),
+    "ramp_m0": (88108, 3.076802642e+00, 1.228036941e-03),
+    "const_m3": (88077, 1.073991490e+01, 1.668861834e-03),
+    "ramp_m3": (88077, 4.196292139e+00, 2.267686650e-03),
+}
+
+
+def _oracle_config(case):
+    base = oracle.read_config_file(oracle.VOICE_MALE)
+    base.update({k: str(v) for k, v in case["overrides"].items()})
+    return oracle.config_from_dict(base, case["rate"], case["delay"])
+
+
+@pytest.mark.parametrize("case", golden_cases.CASES, ids=lambda c: c["name"])
+def test_oracle_matches_reference_vector(case, golden):
+    m = golden["manifest"][case["name"]]
+    tr = golden_cases.track_for(case, golden)
+    cfg = _oracle_config(case)
+    d = oracle.derive(cfg, case["crate"])
+    assert d.sample_rate == int(m["fs"])
+    assert d.control_steps * tr.shape[0] == m["steps"]
+    assert oracle.output_count(cfg, tr.shape[0], case["crate"]) == m["n"]
+    out = oracle.synthesize(cfg, tr, case["crate"])
+    assert out.size == m["n"]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == m["sha256"]
+    if case["store"] == "full":
+        assert np.array_equal(out, golden[case["name"] + "__out"])
+    else:
+        assert np.array_equal(out[:: golden_cases.DIGEST_STRIDE], golden[case["name"] + "__strided"])
+
+
+@pytest.mark.parametrize("name", sorted(KAT))
+def test_survey_known_answers(name, golden):
+    n, total, peak = KAT[name]
+    m = golden["manifest"][name]
+    assert m["n"] == n
+    assert m["sum"] == pytest.approx(total, rel=1e-9)
+    assert m["maxabs"] == pytest.approx(peak, rel=1e-9)
+
+
+def test_derived_constants_male_model0():
+    # SURVEY.md E13
+    d = oracle.derive(oracle.male_config(44100.0), 250.0)
+    assert (d.sample_rate, d.control_steps, d.fir_taps) == (20034, 80, 49)
+    assert (d.table_div1, d.table_div2, d.tn_delta) == (205, 328, 0.0)
+    assert (d.time_register_increment, d.pad_size, d.upsampling) == (29772, 13, 1)
+    d = oracle.derive(oracle.male_config(48000.0), 250.0)
+    assert d.time_register_increment == 27353
+    d = oracle.derive(oracle.male_config(44100.0, section_delay=3), 250.0)
+    assert (d.sample_rate, d.time_register_increment, d.phase_increment, d.pad_size, d.upsampling) == \
+        (60102, 89316, 48087, 18, 0)
+
+
+def test_output_counts_long_form():
+    # 7500 frames (30 s)
+    assert oracle.output_count(oracle.male_config(44100.0), 7500) == 1320815
+    assert oracle.output_count(oracle.male_config(44100.0, section_delay=3), 7500) == 1320785
+    assert oracle.output_count(oracle.male_config(44100.0), 0) == 58  # flush of an empty utterance: ceil(26 * 65536 / 29772)
+
+
+def test_output_scale_rule():
+    # Util::calculateOutputScale: 0.95 / max|x|, and 0 below 1e-30 (VTMUtil.cpp:48-67)
+    x = np.array([0.1, -0.5, 0.25], dtype=np.float32)
+    assert oracle.output_scale(x) == pytest.approx(np.float32(0.95) / np.float32(0.5))
+    assert oracle.output_scale(np.zeros(8, dtype=np.float32)) == 0.0
+
+
+def test_noise_sequence_is_utterance_independent():
+    import ctypes
+    buf = np.empty(64, dtype=np.float64)
+    oracle.lib().vtmo_noise_sequence(buf.ctypes.data, buf.size)
+    seed = 0.7892347
+    x1 = 0.0
+    for i in range(64):
+        p = seed * 377.0
+        seed = p - int(p)
+        w = seed - 0.5
+        assert buf[i] == w + x1
+        x1 = w

@@ -1,0 +1,62 @@
+"""Deterministic synthetic VTM parameter tracks (test + bench inputs).
+
+Frame layout follows the reference's parameter order (VocalTractModel0.h:160-178):
+pitch, glotVol, aspVol, fricVol, fricPos, fricCF, fricBW, r1..r8, velum.
+The `const`/`ramp` recipes are the known-answer tracks of SURVEY.md section 0;
+`random_tracks` is the generator of SURVEY.md 8(d) config 2/3 (ranges from the
+reference's data/voice/english/0_male/interactive.txt).
+"""
+import numpy as np
+
+N_PARAM = 16
+
+A = np.array([-12, 60, 0, 0, 5.5, 2500, 500, 0.8, 0.65, 0.65, 0.65, 1.31, 1.23, 1.31, 1.67, 0.1],
+             dtype=np.float64)
+B = np.array([-5, 40, 20, 30, 6.7, 4500, 2000, 0.8, 1.2, 1.0, 0.4, 0.9, 0.3, 1.5, 0.9, 1.0],
+             dtype=np.float64)
+
+
+def const_track(frames=500):
+    return np.tile(A.astype(np.float32), (frames, 1))
+
+
+def ramp_track(frames=500):
+    i = np.arange(frames, dtype=np.float64)[:, None]
+    return (A + (B - A) * i / (frames - 1)).astype(np.float32)
+
+
+# (lo, hi) per parameter — editor ranges
+_RANGES = np.array([
+    (-20, 0), (40, 60), (0, 20), (0, 30), (0, 7), (100, 5500), (250, 4500),
+    (0.1, 3.0), (0.1, 3.0), (0.1, 3.0), (0.1, 3.0), (0.1, 3.0), (0.1, 3.0), (0.1, 3.0), (0.1, 3.0),
+    (0.1, 1.5)], dtype=np.float64)
+
+
+def random_track(frames, seed, consonant_heavy=False):
+    """Piecewise-linear track between random key-frames every 20-60 frames."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    keys_t = [0]
+    while keys_t[-1] < frames - 1:
+        keys_t.append(min(frames - 1, keys_t[-1] + int(rng.integers(20, 61))))
+    keys_t = np.array(keys_t)
+    nk = len(keys_t)
+    u = rng.random((nk, N_PARAM))
+    vals = _RANGES[:, 0] + u * (_RANGES[:, 1] - _RANGES[:, 0])
+    unvoiced = rng.random(nk) < 0.3
+    vals[unvoiced, 1] = 0.0
+    if consonant_heavy:
+        m = rng.random(nk) < 0.5
+        vals[m, 15] = 0.5 + rng.random(m.sum()) * 1.0          # velum >= 0.5
+        m = rng.random(nk) < 0.5
+        vals[m, 3] = 20.0 + rng.random(m.sum()) * 10.0         # fricVol >= 20
+        m = rng.random(nk) < 0.3
+        vals[m, 2] = 10.0 + rng.random(m.sum()) * 10.0         # aspVol >= 10
+    t = np.arange(frames)
+    out = np.empty((frames, N_PARAM), dtype=np.float64)
+    for p in range(N_PARAM):
+        out[:, p] = np.interp(t, keys_t, vals[:, p])
+    return out.astype(np.float32)
+
+
+def random_tracks(batch, frames, seed0=1000, consonant_heavy=False):
+    return np.stack([random_track(frames, seed0 + b, consonant_heavy) for b in range(batch)])
