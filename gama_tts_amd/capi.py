@@ -1,0 +1,240 @@
+"""ctypes binding of include/gama_vtm.h.  No computation happens here."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libgama_vtm.so"
+N_PARAM = 16
+DEVICE_NONE = -1
+PRECISION_F64 = 0
+PRECISION_MIXED = 1
+TABLE_FIR, TABLE_SRC_H, TABLE_SRC_DH, TABLE_WAVETABLE = 0, 1, 2, 3
+_STATUS_UNSUPPORTED = 4
+
+
+class GvtmError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("gvtm status %d: %s" % (status, message))
+        self.status = status
+
+
+class Config(ctypes.Structure):
+    _fields_ = [
+        ("output_rate", ctypes.c_double),
+        ("waveform", ctypes.c_int32),
+        ("noise_modulation", ctypes.c_int32),
+        ("glottal_pulse_tp", ctypes.c_double),
+        ("glottal_pulse_tn_min", ctypes.c_double),
+        ("glottal_pulse_tn_max", ctypes.c_double),
+        ("breathiness", ctypes.c_double),
+        ("vocal_tract_length_offset", ctypes.c_double),
+        ("vocal_tract_length", ctypes.c_double),
+        ("temperature", ctypes.c_double),
+        ("loss_factor", ctypes.c_double),
+        ("mouth_coefficient", ctypes.c_double),
+        ("nose_coefficient", ctypes.c_double),
+        ("throat_cutoff", ctypes.c_double),
+        ("throat_volume", ctypes.c_double),
+        ("mix_offset", ctypes.c_double),
+        ("global_radius_coef", ctypes.c_double),
+        ("global_nasal_radius_coef", ctypes.c_double),
+        ("aperture_radius", ctypes.c_double),
+        ("nasal_radius", ctypes.c_double * 5),
+        ("radius_coef", ctypes.c_double * 8),
+        ("section_delay", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+    ]
+
+
+class Info(ctypes.Structure):
+    _fields_ = [
+        ("internal_sample_rate", ctypes.c_int32),
+        ("control_steps", ctypes.c_uint32),
+        ("output_rate", ctypes.c_double),
+        ("control_rate", ctypes.c_double),
+        ("fir_taps", ctypes.c_int32),
+        ("time_register_increment", ctypes.c_uint32),
+        ("phase_increment", ctypes.c_uint32),
+        ("pad_size", ctypes.c_int32),
+        ("upsampling", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+        ("section_delay", ctypes.c_int32),
+    ]
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", _LIB_NAME)
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libgama_vtm.so from the in-tree build; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C gama_tts_amd/csrc). There is no fallback path." % path)
+    L = ctypes.CDLL(path)
+    vp, sz, dbl, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_int
+    L.gvtm_status_string.restype = ctypes.c_char_p
+    L.gvtm_status_string.argtypes = [i32]
+    L.gvtm_last_error.restype = ctypes.c_char_p
+    L.gvtm_device_count.restype = i32
+    L.gvtm_plan_create.argtypes = [ctypes.POINTER(Config), dbl, i32, ctypes.POINTER(vp)]
+    L.gvtm_plan_create.restype = i32
+    L.gvtm_plan_destroy.argtypes = [vp]
+    L.gvtm_plan_destroy.restype = None
+    L.gvtm_plan_info.argtypes = [vp, ctypes.POINTER(Info)]
+    L.gvtm_plan_info.restype = i32
+    L.gvtm_plan_table.argtypes = [vp, i32, vp, sz]
+    L.gvtm_plan_table.restype = i32
+    L.gvtm_output_count.argtypes = [vp, sz]
+    L.gvtm_output_count.restype = sz
+    L.gvtm_synthesize_batch_device.argtypes = [vp, vp, vp, sz, sz, vp, sz, vp, vp, vp]
+    L.gvtm_synthesize_batch_device.restype = i32
+    L.gvtm_synthesize_batch_host.argtypes = [vp, vp, vp, sz, sz, vp, sz, vp, vp]
+    L.gvtm_synthesize_batch_host.restype = i32
+    L.gvtm_normalize_batch_device.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp, vp]
+    L.gvtm_normalize_batch_device.restype = i32
+    L.gvtm_plan_set_timing.argtypes = [vp, i32]
+    L.gvtm_plan_set_timing.restype = i32
+    L.gvtm_plan_take_kernel_ms.argtypes = [vp, ctypes.POINTER(i32)]
+    L.gvtm_plan_take_kernel_ms.restype = dbl
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(load_library().gvtm_device_count())
+
+
+def read_config_file(path):
+    """`key = value` lines, `#` comments — the reference's ConfigurationData file format
+    (gama_tts/src/ConfigurationData.cpp:67-118)."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if not line or line.startswith("#"):
+                continue
+            key, value = line.split("=", 1)
+            out[key.strip()] = value.strip()
+    return out
+
+
+def config_from_dict(d, output_rate=None, section_delay=1, precision=PRECISION_F64):
+    """Builds a gvtm_config from the merged vtm.txt + variant keys (VocalTractModel0.h:266-305)."""
+    c = Config()
+    c.output_rate = float(d["output_rate"]) if output_rate is None else float(output_rate)
+    c.waveform = int(float(d["waveform"]))
+    c.noise_modulation = int(float(d["noise_modulation"]))
+    for key in ("glottal_pulse_tp", "glottal_pulse_tn_min", "glottal_pulse_tn_max", "breathiness",
+                "vocal_tract_length_offset", "vocal_tract_length", "temperature", "loss_factor",
+                "mouth_coefficient", "nose_coefficient", "throat_cutoff", "throat_volume", "mix_offset",
+                "global_radius_coef", "global_nasal_radius_coef", "aperture_radius"):
+        setattr(c, key, float(d[key]))
+    for i in range(5):
+        c.nasal_radius[i] = float(d["nasal_radius_%d" % (i + 1)])
+    for i in range(8):
+        c.radius_coef[i] = float(d["radius_%d_coef" % (i + 1)])
+    c.section_delay = int(section_delay)
+    c.precision = int(precision)
+    return c
+
+
+def _ptr(x):
+    """Device/host pointer of a torch tensor, numpy array, int or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return ctypes.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        return ctypes.c_void_p(x.ctypes.data)
+    return ctypes.c_void_p(x.data_ptr())  # torch.Tensor
+
+
+class Plan:
+    """Owns a gvtm_plan.  device=DEVICE_NONE gives a design-only plan (no GPU needed)."""
+
+    def __init__(self, config, control_rate=250.0, device=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self.config = config
+        rc = self._lib.gvtm_plan_create(ctypes.byref(config), float(control_rate), int(device), ctypes.byref(self._h))
+        self._check(rc)
+        info = Info()
+        self._check(self._lib.gvtm_plan_info(self._h, ctypes.byref(info)))
+        self.info = info
+
+    def _check(self, rc):
+        if rc != 0:
+            raise GvtmError(rc, self._lib.gvtm_last_error().decode() or self._lib.gvtm_status_string(rc).decode())
+
+    def close(self):
+        if self._h:
+            self._lib.gvtm_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def table(self, which):
+        buf = np.empty(4096, dtype=np.float64)
+        n = self._lib.gvtm_plan_table(self._h, which, buf.ctypes.data, buf.size)
+        if n < 0:
+            self._check(-n)
+        return buf[:n].copy()
+
+    def output_count(self, frames):
+        n = self._lib.gvtm_output_count(self._h, int(frames))
+        if n == ctypes.c_size_t(-1).value:
+            raise GvtmError(_STATUS_UNSUPPORTED, self._lib.gvtm_last_error().decode())
+        return int(n)
+
+    def set_timing(self, enabled):
+        self._check(self._lib.gvtm_plan_set_timing(self._h, int(bool(enabled))))
+
+    def take_kernel_ms(self):
+        n = ctypes.c_int(0)
+        ms = self._lib.gvtm_plan_take_kernel_ms(self._h, ctypes.byref(n))
+        return float(ms), int(n.value)
+
+    def synthesize_device(self, d_params, batch, max_frames, d_audio, audio_stride, d_frame_counts=None,
+                          d_out_counts=None, d_maxabs=None, stream=None):
+        """All arguments are device pointers (torch CUDA tensors or raw ints)."""
+        self._check(self._lib.gvtm_synthesize_batch_device(
+            self._h, _ptr(d_params), _ptr(d_frame_counts), int(batch), int(max_frames), _ptr(d_audio),
+            int(audio_stride), _ptr(d_out_counts), _ptr(d_maxabs), _ptr(stream)))
+
+    def synthesize_host(self, params, frame_counts=None):
+        """params: float32 [B][F][16] numpy -> (audio float32 [B][stride], counts int64 [B], maxabs float32 [B])."""
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        assert params.ndim == 3 and params.shape[2] == N_PARAM
+        batch, frames = params.shape[:2]
+        stride = self.output_count(frames)
+        audio = np.zeros((batch, stride), dtype=np.float32)
+        counts = np.zeros(batch, dtype=np.int64)
+        maxabs = np.zeros(batch, dtype=np.float32)
+        fc = None
+        if frame_counts is not None:
+            fc = np.ascontiguousarray(frame_counts, dtype=np.int32)
+            assert fc.shape == (batch,)
+        self._check(self._lib.gvtm_synthesize_batch_host(
+            self._h, _ptr(params), _ptr(fc), batch, frames, _ptr(audio), stride, _ptr(counts), _ptr(maxabs)))
+        return audio, counts, maxabs
+
+    def normalize_device(self, d_audio, batch, audio_stride, d_maxabs, d_counts=None, d_out_f32=None, d_out_i16=None,
+                         d_scales=None, stream=None):
+        self._check(self._lib.gvtm_normalize_batch_device(
+            self._h, _ptr(d_audio), int(batch), int(audio_stride), _ptr(d_counts), _ptr(d_maxabs), _ptr(d_out_f32),
+            _ptr(d_out_i16), _ptr(d_scales), _ptr(stream)))

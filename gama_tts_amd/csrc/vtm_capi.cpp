@@ -1,0 +1,383 @@
+// C ABI of libgama_vtm.so (see include/gama_vtm.h).  Host side only: validation, table
+// design/upload, launches.  No exception crosses the extern "C" frame (the reference's
+// plugin convention: construct returns nullptr, VocalTractModelPlugin.cpp:87-90).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gama_vtm.h"
+#include "vtm_design.hpp"
+#include "vtm_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string& msg)
+{
+	g_last_error = msg;
+	return status;
+}
+
+int fail_hip(hipError_t e, const char* what)
+{
+	return fail(GVTM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+struct DeviceBuffer {
+	void* ptr = nullptr;
+	size_t bytes = 0;
+	hipError_t ensure(size_t need)
+	{
+		if (need <= bytes) return hipSuccess;
+		if (ptr) (void) hipFree(ptr);
+		ptr = nullptr;
+		bytes = 0;
+		hipError_t e = hipMalloc(&ptr, need);
+		if (e == hipSuccess) bytes = need;
+		return e;
+	}
+	void release()
+	{
+		if (ptr) (void) hipFree(ptr);
+		ptr = nullptr;
+		bytes = 0;
+	}
+};
+
+struct EventPair {
+	hipEvent_t start = nullptr, stop = nullptr;
+};
+
+} // namespace
+
+struct gvtm_plan {
+	gvtm::Design design;
+	int device = 0;
+	bool mixed = false;
+	double* d_wavetable = nullptr;
+	double* d_fir = nullptr;
+	double* d_src_h = nullptr;
+	double* d_src_dh = nullptr;
+	// staging for the host-buffer entry point
+	DeviceBuffer s_params, s_frames, s_audio, s_counts, s_maxabs;
+	// kernel timing (HIP events on the launch stream)
+	bool timing = false;
+	std::vector<EventPair> pending;
+	std::vector<EventPair> pool;
+};
+
+namespace {
+
+template <typename T>
+hipError_t upload(T** dst, const std::vector<T>& src)
+{
+	hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), sizeof(T) * src.size());
+	if (e != hipSuccess) return e;
+	return hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice);
+}
+
+void free_plan(gvtm_plan* p)
+{
+	if (!p) return;
+	if (p->device == GVTM_DEVICE_NONE) {
+		delete p;
+		return;
+	}
+	(void) hipSetDevice(p->device);
+	if (p->d_wavetable) (void) hipFree(p->d_wavetable);
+	if (p->d_fir) (void) hipFree(p->d_fir);
+	if (p->d_src_h) (void) hipFree(p->d_src_h);
+	if (p->d_src_dh) (void) hipFree(p->d_src_dh);
+	p->s_params.release();
+	p->s_frames.release();
+	p->s_audio.release();
+	p->s_counts.release();
+	p->s_maxabs.release();
+	for (auto& ev : p->pending) { (void) hipEventDestroy(ev.start); (void) hipEventDestroy(ev.stop); }
+	for (auto& ev : p->pool) { (void) hipEventDestroy(ev.start); (void) hipEventDestroy(ev.stop); }
+	delete p;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* gvtm_status_string(int status)
+{
+	switch (status) {
+	case GVTM_OK: return "ok";
+	case GVTM_ERR_INVALID_ARGUMENT: return "invalid argument";
+	case GVTM_ERR_NO_DEVICE: return "no HIP device";
+	case GVTM_ERR_HIP: return "HIP runtime error";
+	case GVTM_ERR_UNSUPPORTED: return "unsupported";
+	case GVTM_ERR_OUT_OF_MEMORY: return "out of memory";
+	default: return "unknown status";
+	}
+}
+
+const char* gvtm_last_error(void)
+{
+	return g_last_error.c_str();
+}
+
+int gvtm_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int gvtm_plan_create(const gvtm_config* config, double control_rate, int device, gvtm_plan** plan_out)
+{
+	if (!config || !plan_out) return fail(GVTM_ERR_INVALID_ARGUMENT, "null config or plan_out");
+	*plan_out = nullptr;
+	try {
+		std::unique_ptr<gvtm_plan, void (*)(gvtm_plan*)> plan(new gvtm_plan, free_plan);
+		const std::string why = gvtm::design_plan(*config, control_rate, plan->design);
+		if (!why.empty()) return fail(GVTM_ERR_INVALID_ARGUMENT, why);
+		plan->mixed = config->precision == GVTM_PRECISION_MIXED;
+
+		if (device == GVTM_DEVICE_NONE) {
+			// design-only plan: info, tables and output counts work, synthesis reports NO_DEVICE
+			plan->device = GVTM_DEVICE_NONE;
+			*plan_out = plan.release();
+			return GVTM_OK;
+		}
+		int n = 0;
+		hipError_t e = hipGetDeviceCount(&n);
+		if (e != hipSuccess || n <= 0) {
+			return fail(GVTM_ERR_NO_DEVICE, "no HIP device available (libgama_vtm has no CPU path)");
+		}
+		if (device < 0 || device >= n) return fail(GVTM_ERR_NO_DEVICE, "device index out of range");
+		plan->device = device;
+		if ((e = hipSetDevice(device)) != hipSuccess) return fail_hip(e, "hipSetDevice");
+		hipDeviceProp_t prop;
+		if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail_hip(e, "hipGetDeviceProperties");
+		if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+			return fail(GVTM_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+		}
+		if ((e = upload(&plan->d_wavetable, plan->design.wavetable)) != hipSuccess) return fail_hip(e, "upload wavetable");
+		if ((e = upload(&plan->d_fir, plan->design.fir)) != hipSuccess) return fail_hip(e, "upload fir");
+		if ((e = upload(&plan->d_src_h, plan->design.src_h)) != hipSuccess) return fail_hip(e, "upload src_h");
+		if ((e = upload(&plan->d_src_dh, plan->design.src_dh)) != hipSuccess) return fail_hip(e, "upload src_dh");
+		*plan_out = plan.release();
+		return GVTM_OK;
+	} catch (const std::bad_alloc&) {
+		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
+	} catch (const std::exception& ex) {
+		return fail(GVTM_ERR_INVALID_ARGUMENT, ex.what());
+	}
+}
+
+void gvtm_plan_destroy(gvtm_plan* plan)
+{
+	free_plan(plan);
+}
+
+int gvtm_plan_info(const gvtm_plan* plan, gvtm_info* info)
+{
+	if (!plan || !info) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan or info");
+	const gvtm::DeviceConstants& k = plan->design.k;
+	info->internal_sample_rate = k.sample_rate;
+	info->control_steps = k.control_steps;
+	info->output_rate = plan->design.config.output_rate;
+	info->control_rate = plan->design.control_rate;
+	info->fir_taps = k.fir_taps;
+	info->time_register_increment = k.time_inc;
+	info->phase_increment = k.phase_inc;
+	info->pad_size = k.pad;
+	info->upsampling = k.upsampling;
+	info->device = plan->device;
+	info->precision = plan->mixed ? GVTM_PRECISION_MIXED : GVTM_PRECISION_F64;
+	info->section_delay = k.section_delay;
+	return GVTM_OK;
+}
+
+int gvtm_plan_table(const gvtm_plan* plan, int which, double* out, size_t capacity)
+{
+	if (!plan || !out) return -fail(GVTM_ERR_INVALID_ARGUMENT, "null plan or out");
+	const std::vector<double>* src = nullptr;
+	switch (which) {
+	case GVTM_TABLE_FIR: src = &plan->design.fir; break;
+	case GVTM_TABLE_SRC_H: src = &plan->design.src_h; break;
+	case GVTM_TABLE_SRC_DH: src = &plan->design.src_dh; break;
+	case GVTM_TABLE_WAVETABLE: src = &plan->design.wavetable; break;
+	default: return -fail(GVTM_ERR_INVALID_ARGUMENT, "unknown table");
+	}
+	if (capacity < src->size()) return -fail(GVTM_ERR_INVALID_ARGUMENT, "table buffer too small");
+	std::memcpy(out, src->data(), sizeof(double) * src->size());
+	return static_cast<int>(src->size());
+}
+
+size_t gvtm_output_count(const gvtm_plan* plan, size_t n_frames)
+{
+	if (!plan) return static_cast<size_t>(-1);
+	uint64_t n = 0;
+	if (!gvtm::output_count_for_steps(plan->design.k, static_cast<uint64_t>(n_frames) * plan->design.k.control_steps, n)) {
+		g_last_error = "this frame count triggers the reference SampleRateConverter's flush overrun (ring-wrap defect); not reproduced";
+		return static_cast<size_t>(-1);
+	}
+	return static_cast<size_t>(n);
+}
+
+int gvtm_plan_set_timing(gvtm_plan* plan, int enabled)
+{
+	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
+	plan->timing = enabled != 0;
+	return GVTM_OK;
+}
+
+double gvtm_plan_take_kernel_ms(gvtm_plan* plan, int* launches_out)
+{
+	if (launches_out) *launches_out = 0;
+	if (!plan || plan->device == GVTM_DEVICE_NONE || plan->pending.empty()) return -1.0;
+	(void) hipSetDevice(plan->device);
+	double total = 0.0;
+	int n = 0;
+	for (auto& ev : plan->pending) {
+		float ms = 0.f;
+		if (hipEventSynchronize(ev.stop) == hipSuccess && hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
+			total += ms;
+			++n;
+		}
+		plan->pool.push_back(ev);
+	}
+	plan->pending.clear();
+	if (launches_out) *launches_out = n;
+	return n ? total / n : -1.0;
+}
+
+int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_counts,
+		size_t batch, size_t max_frames, float* d_audio, size_t audio_stride,
+		int64_t* d_out_counts, float* d_maxabs, void* hip_stream)
+{
+	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
+	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan (GVTM_DEVICE_NONE): there is no CPU synthesis path");
+	if (batch == 0) return GVTM_OK;
+	if (!d_audio) return fail(GVTM_ERR_INVALID_ARGUMENT, "null audio buffer");
+	if (max_frames > 0 && !d_params) return fail(GVTM_ERR_INVALID_ARGUMENT, "null params with max_frames > 0");
+	if (batch > 0x7fffffffu) return fail(GVTM_ERR_INVALID_ARGUMENT, "batch too large for one launch");
+	const size_t need = gvtm_output_count(plan, max_frames);
+	if (need == static_cast<size_t>(-1)) return GVTM_ERR_UNSUPPORTED;
+	if (audio_stride < need) {
+		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
+	}
+	if (gvtm::synth_lds_bytes(plan->mixed) > 160 * 1024) return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
+
+	hipError_t e = hipSetDevice(plan->device);
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+
+	gvtm::SynthArgs args;
+	args.k = plan->design.k;
+	args.params = d_params;
+	args.frame_counts = d_frame_counts;
+	args.audio = d_audio;
+	args.out_counts = d_out_counts;
+	args.maxabs = d_maxabs;
+	args.wavetable = plan->d_wavetable;
+	args.fir = plan->d_fir;
+	args.src_h = plan->d_src_h;
+	args.src_dh = plan->d_src_dh;
+	args.max_frames = max_frames;
+	args.audio_stride = audio_stride;
+
+	EventPair ev;
+	if (plan->timing) {
+		if (!plan->pool.empty()) {
+			ev = plan->pool.back();
+			plan->pool.pop_back();
+		} else {
+			if ((e = hipEventCreate(&ev.start)) != hipSuccess) return fail_hip(e, "hipEventCreate");
+			if ((e = hipEventCreate(&ev.stop)) != hipSuccess) return fail_hip(e, "hipEventCreate");
+		}
+		if ((e = hipEventRecord(ev.start, stream)) != hipSuccess) return fail_hip(e, "hipEventRecord");
+	}
+	e = gvtm::launch_synth(args, batch, plan->mixed, stream);
+	if (plan->timing) {
+		(void) hipEventRecord(ev.stop, stream);
+		plan->pending.push_back(ev);
+	}
+	if (e != hipSuccess) return fail_hip(e, "vtm_synth_kernel launch");
+	return GVTM_OK;
+}
+
+int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
+		size_t batch, size_t max_frames, float* audio, size_t audio_stride,
+		int64_t* out_counts, float* maxabs)
+{
+	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
+	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan (GVTM_DEVICE_NONE): there is no CPU synthesis path");
+	if (batch == 0) return GVTM_OK;
+	if (!audio) return fail(GVTM_ERR_INVALID_ARGUMENT, "null audio buffer");
+	if (max_frames > 0 && !params) return fail(GVTM_ERR_INVALID_ARGUMENT, "null params with max_frames > 0");
+	if (frame_counts) {
+		for (size_t b = 0; b < batch; ++b) {
+			if (frame_counts[b] < 0 || static_cast<size_t>(frame_counts[b]) > max_frames) {
+				return fail(GVTM_ERR_INVALID_ARGUMENT, "frame_counts entry outside [0, max_frames]");
+			}
+			if (gvtm_output_count(plan, static_cast<size_t>(frame_counts[b])) == static_cast<size_t>(-1)) return GVTM_ERR_UNSUPPORTED;
+		}
+	}
+	hipError_t e = hipSetDevice(plan->device);
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	const size_t pbytes = sizeof(float) * batch * max_frames * GVTM_N_PARAM;
+	const size_t abytes = sizeof(float) * batch * audio_stride;
+	if ((e = plan->s_params.ensure(pbytes ? pbytes : 16)) != hipSuccess) return fail_hip(e, "hipMalloc params");
+	if ((e = plan->s_audio.ensure(abytes ? abytes : 16)) != hipSuccess) return fail_hip(e, "hipMalloc audio");
+	if ((e = plan->s_counts.ensure(sizeof(int64_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc counts");
+	if ((e = plan->s_maxabs.ensure(sizeof(float) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc maxabs");
+	if (frame_counts && (e = plan->s_frames.ensure(sizeof(int32_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc frames");
+	if (pbytes && (e = hipMemcpy(plan->s_params.ptr, params, pbytes, hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "H2D params");
+	if (frame_counts && (e = hipMemcpy(plan->s_frames.ptr, frame_counts, sizeof(int32_t) * batch, hipMemcpyHostToDevice)) != hipSuccess) {
+		return fail_hip(e, "H2D frame_counts");
+	}
+	const int rc = gvtm_synthesize_batch_device(plan, static_cast<const float*>(plan->s_params.ptr),
+			frame_counts ? static_cast<const int32_t*>(plan->s_frames.ptr) : nullptr, batch, max_frames,
+			static_cast<float*>(plan->s_audio.ptr), audio_stride, static_cast<int64_t*>(plan->s_counts.ptr),
+			static_cast<float*>(plan->s_maxabs.ptr), nullptr);
+	if (rc != GVTM_OK) return rc;
+	if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
+	if ((e = hipMemcpy(audio, plan->s_audio.ptr, abytes, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H audio");
+	if (out_counts && (e = hipMemcpy(out_counts, plan->s_counts.ptr, sizeof(int64_t) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
+		return fail_hip(e, "D2H counts");
+	}
+	if (maxabs && (e = hipMemcpy(maxabs, plan->s_maxabs.ptr, sizeof(float) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
+		return fail_hip(e, "D2H maxabs");
+	}
+	return GVTM_OK;
+}
+
+int gvtm_normalize_batch_device(gvtm_plan* plan, const float* d_audio, size_t batch, size_t audio_stride,
+		const int64_t* d_counts, const float* d_maxabs, float* d_out_f32, int16_t* d_out_i16,
+		float* d_scales, void* hip_stream)
+{
+	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
+	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan (GVTM_DEVICE_NONE)");
+	if (batch == 0 || audio_stride == 0) return GVTM_OK;
+	if (!d_audio || !d_maxabs) return fail(GVTM_ERR_INVALID_ARGUMENT, "null audio or maxabs");
+	if ((d_out_f32 == nullptr) == (d_out_i16 == nullptr)) {
+		return fail(GVTM_ERR_INVALID_ARGUMENT, "exactly one of d_out_f32 / d_out_i16 must be given");
+	}
+	if (batch > 65535) return fail(GVTM_ERR_INVALID_ARGUMENT, "normalize: batch above 65535 per call");
+	hipError_t e = hipSetDevice(plan->device);
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	gvtm::NormalizeArgs args;
+	args.audio = d_audio;
+	args.counts = d_counts;
+	args.maxabs = d_maxabs;
+	args.out_f32 = d_out_f32;
+	args.out_i16 = d_out_i16;
+	args.scales = d_scales;
+	args.audio_stride = audio_stride;
+	e = gvtm::launch_normalize(args, batch, static_cast<hipStream_t>(hip_stream));
+	if (e != hipSuccess) return fail_hip(e, "vtm_normalize_kernel launch");
+	return GVTM_OK;
+}
+
+} // extern "C"

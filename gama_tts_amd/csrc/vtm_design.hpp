@@ -1,0 +1,80 @@
+// Host-side design of everything that is fixed for a voice configuration:
+// derived rates, filter constants and the fp64 tables the device kernels stage
+// in LDS.  All of it is computed in fp64 on the host exactly once per plan
+// (design tables must be fp64 even for the mixed-precision path).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/gama_vtm.h"
+
+namespace gvtm {
+
+constexpr int kWavetableLength = 512;   // WavetableGlottalSource.h:91
+constexpr int kSrcZeroCrossings = 13;   // SampleRateConverter.h:49
+constexpr int kSrcPhases = 256;         // L_RANGE, SampleRateConverter.h:46
+constexpr int kSrcFilterLength = kSrcZeroCrossings * kSrcPhases; // 3328
+constexpr int kSrcRing = 1024;          // BUFFER_SIZE, SampleRateConverter.h:44
+constexpr int kMaxFirTaps = 64;
+constexpr int kMaxSectionDelay = 4;
+constexpr int kMaxPad = 96;
+
+// Everything the kernels need besides the tables; plain data, copied to the device by value.
+struct DeviceConstants {
+	// rates and driver loop
+	int sample_rate;          // internal rate
+	unsigned control_steps;   // steps per frame
+	float interp_coef;        // 1.0f / control_steps (float32, Controller.cpp:287)
+	int section_delay;
+	// sources
+	int waveform;             // 0 pulse, 1 sine
+	int modulation;
+	unsigned table_div1, table_div2;
+	double tn_delta;          // 0 => static wavetable
+	double basic_increment;   // 512 / fs
+	double breathiness;       // breathiness / 100
+	double crossmix_factor;   // 1 / amp60(mix_offset)
+	int fir_taps;
+	// tube
+	double damping;
+	double radius_coef[8];
+	double aperture_radius2;  // apertureRadius^2
+	double nasal_r2_sq;       // nasalRadius[N2]^2 (first nasal junction)
+	double nasal_k[6];        // fixed nasal coefficients; [0] unused (time varying)
+	double mouth_b0_refl, mouth_a1_refl, mouth_a_rad; // ReflectionFilter / RadiationFilter constants
+	double nose_b0_refl, nose_a1_refl, nose_a_rad;
+	double throat_b0, throat_a1, throat_gain;
+	double bp_T;              // 1 / fs for BandpassFilter::update
+	// sample-rate converter
+	int upsampling;
+	int pad;
+	unsigned time_inc;        // timeRegisterIncrement_
+	unsigned phase_inc;       // phaseIncrement_ (down-sampling)
+	double src_ratio;         // sampleRateRatio_
+};
+
+struct Design {
+	gvtm_config config;
+	double control_rate;
+	DeviceConstants k;
+	std::vector<double> fir;        // fir_taps
+	std::vector<double> src_h;      // 3328
+	std::vector<double> src_dh;     // 3328
+	std::vector<double> wavetable;  // 512
+};
+
+// Returns "" on success, otherwise a description of the offending value.
+std::string design_plan(const gvtm_config& cfg, double control_rate, Design& out);
+
+// Util::amplitude60dB (vtm/VTMUtil.h:48-67)
+double amplitude_60db(double db);
+
+// Output bookkeeping of SampleRateConverter for a track of `steps` internal samples:
+// number of samples after flushBuffer(); returns false when the reference's ring-wrap
+// defect would trigger (see DESIGN.md "SRC flush overrun").
+bool output_count_for_steps(const DeviceConstants& k, uint64_t steps, uint64_t& n_out);
+
+} // namespace gvtm

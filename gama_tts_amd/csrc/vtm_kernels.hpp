@@ -1,0 +1,46 @@
+// Launch interface between the C ABI (vtm_capi.cpp) and the kernels (vtm_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "vtm_design.hpp"
+
+namespace gvtm {
+
+constexpr int kBlock = 256;  // threads per workgroup (4 wavefronts)
+constexpr int kChunk = 192;  // internal-rate steps per chunk; multiple of every supported SectionDelay
+constexpr int kXCap = (2 * kMaxPad) + kChunk + (2 * kMaxPad); // SRC window: history + chunk + flush zeros
+
+struct SynthArgs {
+	DeviceConstants k;
+	const float* params;         // [batch][max_frames][16]
+	const int32_t* frame_counts; // [batch] or null
+	float* audio;                // [batch][audio_stride]
+	int64_t* out_counts;         // [batch] or null
+	float* maxabs;               // [batch] or null
+	const double* wavetable;     // [512]
+	const double* fir;           // [fir_taps]
+	const double* src_h;         // [3328]
+	const double* src_dh;        // [3328]
+	size_t max_frames;
+	size_t audio_stride;
+};
+
+struct NormalizeArgs {
+	const float* audio;
+	const int64_t* counts; // or null
+	const float* maxabs;
+	float* out_f32;        // or null
+	int16_t* out_i16;      // or null
+	float* scales;         // or null
+	size_t audio_stride;
+};
+
+size_t synth_lds_bytes(bool mixed);
+hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, hipStream_t stream);
+hipError_t launch_normalize(const NormalizeArgs& args, size_t batch, hipStream_t stream);
+
+} // namespace gvtm

@@ -1,0 +1,172 @@
+/*
+ * gama_vtm.h — C ABI of the MI355X-native batched vocal-tract-model synthesizer.
+ *
+ * This is the drop-in boundary for GamaTTS's VTM hot path.  Plain C: pointers,
+ * sizes and error codes only (no C++/torch types).  The library behind it
+ * (libgama_vtm.so) is HIP for gfx950; there is no CPU fallback — every entry
+ * point that needs the device fails with GVTM_ERR_NO_DEVICE / GVTM_ERR_HIP
+ * when it is missing.
+ *
+ * Reference interfaces each entry replaces (paths under gama_tts/src/):
+ *
+ *   gvtm_plan_create            VocalTractModel0/2 constructor: loadConfiguration +
+ *                               initializeSynthesizer (vtm/VocalTractModel0.h:255-305, :338-392;
+ *                               vtm/VocalTractModel2.h:322-376, :413-467) for a whole batch
+ *   gvtm_plan_info              VocalTractModel::internalSampleRate/outputSampleRate
+ *                               (vtm/VocalTractModel.h:51-52) and the controlSteps of
+ *                               Controller::synthesize (vtm_control_model/Controller.cpp:286)
+ *   gvtm_output_count           outputBuffer().size() after finishSynthesis()
+ *                               (vtm/VocalTractModel.h:58, vtm/SampleRateConverter.h:462-471)
+ *   gvtm_synthesize_batch_*     Controller::synthesize + VocalTractModel::setAllParameters /
+ *                               execSynthesisStep / finishSynthesis for B utterances
+ *                               (vtm_control_model/Controller.cpp:277-313,
+ *                               vtm/VocalTractModel0.h:396-445, :698-723)
+ *   gvtm_normalize_batch_device Controller::writeOutputToBuffer / writeOutputToFile scaling,
+ *                               Util::calculateOutputScale (Controller.cpp:315-340,
+ *                               vtm/VTMUtil.cpp:48-67, WAVEFileWriter.cpp:122-125)
+ *
+ * The GamaTTS plugin entry points GAMA_TTS_construct_vocal_tract_model /
+ * GAMA_TTS_destruct_vocal_tract_model (vtm/VocalTractModelPlugin.cpp:40-50) are
+ * exported by libgama_vtm_plugin.so, which is a thin C++ shim over this ABI
+ * (see include/gama_vtm_plugin.h and INTEGRATION.md).
+ */
+#ifndef GAMA_VTM_H_
+#define GAMA_VTM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVTM_N_PARAM 16 /* pitch, glotVol, aspVol, fricVol, fricPos, fricCF, fricBW, r1..r8, velum
+                           (vtm/VocalTractModel0.h:160-178) */
+
+typedef enum gvtm_status {
+	GVTM_OK = 0,
+	GVTM_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad size, bad configuration value */
+	GVTM_ERR_NO_DEVICE = 2,        /* no HIP device / device index out of range */
+	GVTM_ERR_HIP = 3,              /* a HIP runtime call failed (see gvtm_last_error) */
+	GVTM_ERR_UNSUPPORTED = 4,      /* valid for the reference but not implemented on the device */
+	GVTM_ERR_OUT_OF_MEMORY = 5
+} gvtm_status;
+
+/* Arithmetic the device path computes in. */
+typedef enum gvtm_precision {
+	GVTM_PRECISION_F64 = 0,  /* everything in fp64, like VocalTractModel0<double> */
+	GVTM_PRECISION_MIXED = 1 /* fp64 oscillator phase / noise / design tables, fp32 tube, filters, FIR, SRC */
+} gvtm_precision;
+
+/* The configuration keys VocalTractModel0/2::loadConfiguration reads from the merged
+ * vtm.txt + variant file (vtm/VocalTractModel0.h:266-305), as numbers. */
+typedef struct gvtm_config {
+	double output_rate;
+	int32_t waveform; /* 0 pulse, 1 sine */
+	int32_t noise_modulation;
+	double glottal_pulse_tp;
+	double glottal_pulse_tn_min;
+	double glottal_pulse_tn_max;
+	double breathiness;
+	double vocal_tract_length_offset;
+	double vocal_tract_length;
+	double temperature;
+	double loss_factor;
+	double mouth_coefficient;
+	double nose_coefficient;
+	double throat_cutoff;
+	double throat_volume;
+	double mix_offset;
+	double global_radius_coef;
+	double global_nasal_radius_coef;
+	double aperture_radius;
+	double nasal_radius[5]; /* nasal_radius_1 .. nasal_radius_5 */
+	double radius_coef[8];  /* radius_1_coef .. radius_8_coef */
+	int32_t section_delay;  /* VocalTractModel2's SectionDelay; 1 == VocalTractModel0 (models 0/2), 3 == model 3 */
+	int32_t precision;      /* gvtm_precision */
+} gvtm_config;
+
+typedef struct gvtm_info {
+	int32_t internal_sample_rate; /* Hz, vtm/VocalTractModel0.h:344 */
+	uint32_t control_steps;       /* internal steps per control frame, Controller.cpp:286 */
+	double output_rate;
+	double control_rate;
+	int32_t fir_taps;                 /* glottal-source FIR, WavetableGlottalSourceFIRFilter.h:86 */
+	uint32_t time_register_increment; /* SampleRateConverter.h:145 */
+	uint32_t phase_increment;         /* SampleRateConverter.h:154 (0 when up-sampling) */
+	int32_t pad_size;                 /* SampleRateConverter.h:158-160 */
+	int32_t upsampling;
+	int32_t device;
+	int32_t precision;
+	int32_t section_delay;
+} gvtm_info;
+
+typedef struct gvtm_plan gvtm_plan;
+
+/* device index for a design-only plan: tables, info and output counts are available on a
+ * machine without a GPU; every synthesis entry point returns GVTM_ERR_NO_DEVICE. */
+#define GVTM_DEVICE_NONE (-1)
+
+/* Design-time tables of a plan, for inspection/tests. */
+typedef enum gvtm_table {
+	GVTM_TABLE_FIR = 0,       /* fir_taps doubles */
+	GVTM_TABLE_SRC_H = 1,     /* 3328 doubles */
+	GVTM_TABLE_SRC_DH = 2,    /* 3328 doubles */
+	GVTM_TABLE_WAVETABLE = 3  /* 512 doubles */
+} gvtm_table;
+
+const char* gvtm_status_string(int status);
+/* Message of the last failing call on this thread ("" if none). */
+const char* gvtm_last_error(void);
+/* Number of HIP devices visible (0 when there is none or the runtime is unusable). */
+int gvtm_device_count(void);
+
+/* Validates the configuration, designs the tables on the host (fp64) and uploads them to
+ * `device`.  control_rate is 1000 / control_period Hz (VTMControlModelConfiguration.cpp:41). */
+int gvtm_plan_create(const gvtm_config* config, double control_rate, int device, gvtm_plan** plan_out);
+void gvtm_plan_destroy(gvtm_plan* plan);
+int gvtm_plan_info(const gvtm_plan* plan, gvtm_info* info_out);
+/* Copies a design table into out[capacity]; returns the element count or a negative status. */
+int gvtm_plan_table(const gvtm_plan* plan, int which, double* out, size_t capacity);
+
+/* Samples finishSynthesis() leaves for an utterance of n_frames frames; (size_t)-1 when the
+ * frame count is not representable (see GVTM_ERR_UNSUPPORTED in DESIGN.md). */
+size_t gvtm_output_count(const gvtm_plan* plan, size_t n_frames);
+
+/*
+ * Batch synthesis, everything resident in device memory.
+ *   d_params       [batch][max_frames][16] float32, reference frame order
+ *   d_frame_counts [batch] int32 frames per utterance (<= max_frames), or NULL: all max_frames
+ *   d_audio        [batch][audio_stride] float32, unscaled samples as in outputBuffer();
+ *                  audio_stride >= gvtm_output_count(plan, max_frames)
+ *   d_out_counts   [batch] int64 samples written per utterance, may be NULL
+ *   d_maxabs       [batch] float32 max|x| per utterance, may be NULL
+ *   hip_stream     hipStream_t (NULL = default stream); the call only enqueues work
+ */
+int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_counts,
+		size_t batch, size_t max_frames, float* d_audio, size_t audio_stride,
+		int64_t* d_out_counts, float* d_maxabs, void* hip_stream);
+
+/* Same with host buffers (H2D, kernel, D2H, synchronous).  frame_counts may be NULL. */
+int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
+		size_t batch, size_t max_frames, float* audio, size_t audio_stride,
+		int64_t* out_counts, float* maxabs);
+
+/* Output scaling of Controller::writeOutputToBuffer / writeOutputToFile: scale = 0.95 / max|x|
+ * (0 when max < 1e-30).  Exactly one of d_out_f32 / d_out_i16 may be non-NULL; i16 applies the
+ * WAVEFileWriter rounding round(x * 32767). d_counts may be NULL (then audio_stride samples). */
+int gvtm_normalize_batch_device(gvtm_plan* plan, const float* d_audio, size_t batch, size_t audio_stride,
+		const int64_t* d_counts, const float* d_maxabs, float* d_out_f32, int16_t* d_out_i16,
+		float* d_scales, void* hip_stream);
+
+/* Average device time (ms) of the dominant synthesis kernel over the launches since the last
+ * call, measured with HIP events on the launch stream; resets the accumulator.  Timing must
+ * have been enabled with gvtm_plan_set_timing(plan, 1).  Returns < 0 when nothing was timed. */
+int gvtm_plan_set_timing(gvtm_plan* plan, int enabled);
+double gvtm_plan_take_kernel_ms(gvtm_plan* plan, int* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* GAMA_VTM_H_ */

@@ -1,0 +1,103 @@
+"""Host-side checks that need no GPU: the library loads, exports the whole C ABI, the
+design tables equal the oracle's bit for bit, and device entry points refuse to run."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gama_tts_amd as g
+from gama_tts_amd import capi
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gvtm_[a-z_0-9]+|GAMA_TTS_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = g.load_library()
+    names = _declared_symbols("gama_vtm.h")
+    assert "gvtm_synthesize_batch_device" in names and len(names) >= 12
+    for name in names:
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.parametrize("delay,rate", [(1, 44100.0), (1, 48000.0), (2, 44100.0), (3, 44100.0), (1, 16000.0)])
+def test_design_matches_oracle_bit_for_bit(delay, rate):
+    d = g.read_config_file(oracle.VOICE_MALE)
+    plan = g.Plan(g.config_from_dict(d, rate, delay), 250.0, capi.DEVICE_NONE)
+    ocfg = oracle.male_config(rate, delay)
+    od = oracle.derive(ocfg)
+    i = plan.info
+    assert (i.internal_sample_rate, i.control_steps, i.fir_taps) == (od.sample_rate, od.control_steps, od.fir_taps)
+    assert (i.time_register_increment, i.phase_increment, i.pad_size, i.upsampling) == \
+        (od.time_register_increment, od.phase_increment, od.pad_size, od.upsampling)
+    fir = np.empty(401)
+    n = oracle.lib().vtmo_fir_coefficients(fir.ctypes.data)
+    h, dh, wt = np.empty(3328), np.empty(3328), np.empty(512)
+    oracle.lib().vtmo_src_filter(h.ctypes.data, dh.ctypes.data)
+    oracle.lib().vtmo_wavetable(ctypes.byref(ocfg), od.sample_rate, wt.ctypes.data)
+    assert np.array_equal(plan.table(capi.TABLE_FIR), fir[:n])
+    assert np.array_equal(plan.table(capi.TABLE_SRC_H), h)
+    assert np.array_equal(plan.table(capi.TABLE_SRC_DH), dh)
+    assert np.array_equal(plan.table(capi.TABLE_WAVETABLE), wt)
+    for frames in (0, 1, 2, 3, 13, 100, 500, 7500):
+        assert plan.output_count(frames) == oracle.output_count(ocfg, frames)
+
+
+def test_output_count_sweep_against_oracle_ring_logic():
+    """Closed form vs the literal ring-buffer walk, incl. the down-sampling flush overrun
+    (SampleRateConverter.h:298-308) that the product refuses instead of reproducing."""
+    d = g.read_config_file(oracle.VOICE_MALE)
+    refused_total = 0
+    for delay, rate, crate, span in ((3, 44100.0, 250.0, 260), (1, 16000.0, 250.0, 260), (1, 44100.0, 250.0, 260),
+                                     (3, 16000.0, 1000.0, 700), (3, 11025.0, 1000.0, 300)):
+        plan = g.Plan(g.config_from_dict(d, rate, delay), crate, capi.DEVICE_NONE)
+        ocfg = oracle.male_config(rate, delay)
+        i = plan.info
+        for frames in range(0, span):
+            want = oracle.output_count(ocfg, frames, crate)
+            fills = frames * i.control_steps + 2 * i.pad_size
+            closed = -((-(fills << 16)) // i.time_register_increment)
+            try:
+                got = plan.output_count(frames)
+            except g.GvtmError as e:
+                assert e.status == 4
+                refused_total += 1
+                # the literal walk converts about one ring (1024 input samples) of stale data more
+                assert want > closed and abs((want - closed) * i.time_register_increment / 65536.0 - 1024) < 8
+                continue
+            assert got == want == closed, (delay, rate, frames)
+    assert refused_total >= 3
+
+
+def test_invalid_configurations_are_rejected():
+    d = g.read_config_file(oracle.VOICE_MALE)
+    for key, value in (("output_rate", 0.0), ("nasal_radius_2", 0.0), ("glottal_pulse_tp", 0.0), ("mix_offset", 0.0)):
+        bad = dict(d)
+        bad[key] = str(value)
+        with pytest.raises(g.GvtmError) as ei:
+            g.Plan(g.config_from_dict(bad), 250.0, capi.DEVICE_NONE)
+        assert ei.value.status == 1
+    with pytest.raises(g.GvtmError):
+        g.Plan(g.config_from_dict(d, section_delay=9), 250.0, capi.DEVICE_NONE)
+    with pytest.raises(g.GvtmError):
+        g.Plan(g.config_from_dict(d), 0.0, capi.DEVICE_NONE)
+
+
+def test_no_cpu_synthesis_path():
+    d = g.read_config_file(oracle.VOICE_MALE)
+    plan = g.Plan(g.config_from_dict(d), 250.0, capi.DEVICE_NONE)
+    with pytest.raises(g.GvtmError) as ei:
+        plan.synthesize_host(np.zeros((1, 2, 16), np.float32))
+    assert ei.value.status == 2  # GVTM_ERR_NO_DEVICE
+    if g.device_count() == 0:
+        with pytest.raises(g.GvtmError) as ei:
+            g.Plan(g.config_from_dict(d), 250.0, 0)
+        assert ei.value.status == 2
