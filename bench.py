@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Throughput of the batched VTM hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (parameter frames in HBM -> audio samples in HBM) over
+one batch of synthetic utterances.  N=1 runs BASELINE.json configs[1] (batch 256, 500 frames
+= 2 s, VocalTractModel0 semantics, 44.1 kHz out).  For N>1 the driver starts one process per
+GPU (torch.distributed.run); every rank synthesizes its own batch (weak scaling, independent
+utterances, no data-path collective — SURVEY.md 8e); the only communication is the barrier
+and the MAX of the elapsed time.
+
+Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes per launch (64 B per
+input frame + 4 B per output sample) / the synthesis kernel's mean duration
+measured with HIP events on the launch stream.  `cpu_baseline` times the real reference
+(oracle/_ref, compiled from /root/reference in the build container; "port" = our C oracle when
+that binary is absent) on one host core over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(params, output_rate, delay, budget_s=12.0):
+    """Single-thread CPU throughput (output samples/s) on a bounded sample of the workload."""
+    import numpy as np
+    import oracle
+
+    sample = params[:4]
+    kind = None
+    exe_kind = None
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = f.read()
+    except OSError:
+        pass
+    if oracle.ref_binary("v3") and all(x in flags for x in (" avx2", " fma", " bmi2")):
+        exe_kind = "v3"
+    elif oracle.ref_binary("o3"):
+        exe_kind = "o3"
+    model = {1: "0", 2: "2:2", 3: "3", 4: "2:4"}[delay]
+    if exe_kind:
+        kind = "reference"
+        _, info = oracle.ref_synthesize(sample[0], model, output_rate, 250.0, kind=exe_kind, repeat=2)
+        per_rep = float(info["sec"]) / 2
+        repeat = max(1, int(budget_s / max(per_rep, 1e-6) / len(sample)))
+        total_samples = 0
+        total_sec = 0.0
+        for tr in sample:
+            _, info = oracle.ref_synthesize(tr, model, output_rate, 250.0, kind=exe_kind, repeat=repeat)
+            total_samples += int(info["N"]) * repeat
+            total_sec += float(info["sec"])
+        desc = "%d utterances x %d repeats of %d frames through oracle/_ref/ref_vtm_%s (model %s)" % (
+            len(sample), repeat, sample.shape[1], exe_kind, model)
+    else:
+        kind = "port"
+        cfg = oracle.male_config(output_rate, delay)
+        t0 = time.perf_counter()
+        out = oracle.synthesize(cfg, sample[0])
+        per = time.perf_counter() - t0
+        repeat = max(1, int(budget_s / max(per, 1e-6) / len(sample)))
+        total_samples = 0
+        t0 = time.perf_counter()
+        for tr in sample:
+            for _ in range(repeat):
+                total_samples += oracle.synthesize(cfg, tr).size
+        total_sec = time.perf_counter() - t0
+        desc = "%d utterances x %d repeats of %d frames through oracle/vtm_oracle.c" % (len(sample), repeat, sample.shape[1])
+    return {"value": total_samples / total_sec, "unit": "samples/s", "cores": 1, "kind": kind, "sample": desc}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=500, help="control frames per utterance (4 ms each)")
+    ap.add_argument("--delay", type=int, default=1, help="SectionDelay (1 = VocalTractModel0)")
+    ap.add_argument("--precision", choices=["f64", "mixed"], default="f64")
+    ap.add_argument("--output-rate", type=float, default=44100.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import gama_tts_amd as g
+    from gama_tts_amd import capi
+    import tracks
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the VTM path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    voice = os.path.join(ROOT, "tests", "golden", "voice_male.txt")
+    cfgd = g.read_config_file(voice)
+    prec = capi.PRECISION_F64 if args.precision == "f64" else capi.PRECISION_MIXED
+    plan = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay, prec), 250.0, local_rank)
+    n_out = plan.output_count(args.frames)
+
+    # synthetic tracks: SURVEY.md 8(d) config-2 generator; a pool of distinct tracks is tiled
+    # over the batch so that host-side generation stays cheap for big batches
+    pool = min(args.batch, 256)
+    host_pool = tracks.random_tracks(pool, args.frames, seed0=1000 + 100000 * rank)
+    reps = (args.batch + pool - 1) // pool
+    d_pool = torch.from_numpy(host_pool).to(dev)
+    d_params = d_pool.repeat((reps, 1, 1))[: args.batch].contiguous()
+    d_audio = torch.empty((args.batch, n_out), dtype=torch.float32, device=dev)
+    d_counts = torch.zeros(args.batch, dtype=torch.int64, device=dev)
+    d_max = torch.zeros(args.batch, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        plan.synthesize_device(d_params, args.batch, args.frames, d_audio, n_out, None, d_counts, d_max, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    plan.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = plan.take_kernel_ms()
+    plan.set_timing(False)
+    assert int(d_counts.min().item()) == n_out and int(d_counts.max().item()) == n_out
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = float(n_out) * args.batch * world * args.steps
+    value = total_samples / elapsed
+    algo_bytes = float(args.batch) * (args.frames * 64.0 + n_out * 4.0)
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+
+    if rank == 0:
+        line = {
+            "metric": "audio samples/sec (whole node), batched VTM @44.1kHz",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if args.precision == "f64" else "f32",
+            "data": "synthetic",
+            "real_time_factor": value / args.output_rate,
+            "config": {
+                "workload": "batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel%s "
+                            "semantics (SectionDelay %d), male voice, %.0f Hz out" % (
+                                args.batch, args.frames, args.frames * 0.004, "0" if args.delay == 1 else "2",
+                                args.delay, args.output_rate),
+                "batch_per_gpu": args.batch,
+                "frames": args.frames,
+                "samples_per_utterance": n_out,
+                "precision": args.precision,
+                "parallelism": "utterance-sharded x%d, no collectives" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": None,
+                "kernel": "vtm_synth_kernel",
+                "kernel_ms": kernel_ms,
+                "launches_timed": launches,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

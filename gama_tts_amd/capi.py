@@ -77,7 +77,15 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    path = library_path()
+    path = os.environ.get("GVTM_LIBRARY") or library_path()
+    # libgama_vtm.so and PyTorch-ROCm both need libamdhip64.so.7 and a process can hold only one
+    # copy: whichever loads first serves both.  PyTorch only works with the copy bundled in its
+    # wheel, so when torch is installed let it load first (bench.py/tests share device pointers
+    # and streams with torch).  C/C++ hosts are unaffected: they use the system ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C gama_tts_amd/csrc). There is no fallback path." % path)

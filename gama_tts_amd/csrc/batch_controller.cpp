@@ -1,0 +1,214 @@
+#include "batch_controller.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace gvtm {
+
+std::map<std::string, std::string> read_key_value_file(const std::string& path)
+{
+	std::ifstream in(path, std::ios_base::binary);
+	if (!in) throw std::runtime_error("Could not open the file: " + path);
+	std::map<std::string, std::string> out;
+	std::string line;
+	int line_no = 0;
+	while (std::getline(in, line)) {
+		++line_no;
+		if (line.empty() || line[0] == '#') continue;
+		const auto eq = line.find('=');
+		if (eq == std::string::npos) throw std::runtime_error(path + ": missing separator on line " + std::to_string(line_no));
+		auto trim = [](std::string s) {
+			const auto b = s.find_first_not_of(" \t\r");
+			const auto e = s.find_last_not_of(" \t\r");
+			return b == std::string::npos ? std::string() : s.substr(b, e - b + 1);
+		};
+		const std::string key = trim(line.substr(0, eq));
+		const std::string value = trim(line.substr(eq + 1));
+		if (key.empty() || value.empty()) throw std::runtime_error(path + ": empty key or value on line " + std::to_string(line_no));
+		if (!out.emplace(key, value).second) throw std::runtime_error(path + ": duplicate key " + key);
+	}
+	return out;
+}
+
+namespace {
+
+double num(const std::map<std::string, std::string>& k, const char* key)
+{
+	auto it = k.find(key);
+	if (it == k.end()) throw std::runtime_error(std::string("Key '") + key + "' not found.");
+	return std::stod(it->second);
+}
+
+} // namespace
+
+gvtm_config config_from_keys(const std::map<std::string, std::string>& k, int precision)
+{
+	gvtm_config c{};
+	const int model = k.count("model") ? static_cast<int>(num(k, "model")) : 0;
+	switch (model) {
+	case 0: case 2: c.section_delay = 1; break;
+	case 3: c.section_delay = 3; break;
+	default:
+		throw std::runtime_error("vocal tract model " + std::to_string(model) +
+				" is not served by the device path (supported: 0, 2, 3)");
+	}
+	if (k.count("section_delay")) c.section_delay = static_cast<int>(num(k, "section_delay"));
+	c.precision = precision;
+	c.output_rate = num(k, "output_rate");
+	c.waveform = static_cast<int>(num(k, "waveform"));
+	c.noise_modulation = static_cast<int>(num(k, "noise_modulation"));
+	c.glottal_pulse_tp = num(k, "glottal_pulse_tp");
+	c.glottal_pulse_tn_min = num(k, "glottal_pulse_tn_min");
+	c.glottal_pulse_tn_max = num(k, "glottal_pulse_tn_max");
+	c.breathiness = num(k, "breathiness");
+	c.vocal_tract_length_offset = num(k, "vocal_tract_length_offset");
+	c.vocal_tract_length = num(k, "vocal_tract_length");
+	c.temperature = num(k, "temperature");
+	c.loss_factor = num(k, "loss_factor");
+	c.mouth_coefficient = num(k, "mouth_coefficient");
+	c.nose_coefficient = num(k, "nose_coefficient");
+	c.throat_cutoff = num(k, "throat_cutoff");
+	c.throat_volume = num(k, "throat_volume");
+	c.mix_offset = num(k, "mix_offset");
+	c.global_radius_coef = num(k, "global_radius_coef");
+	c.global_nasal_radius_coef = num(k, "global_nasal_radius_coef");
+	c.aperture_radius = num(k, "aperture_radius");
+	for (int i = 0; i < 5; ++i) c.nasal_radius[i] = num(k, ("nasal_radius_" + std::to_string(i + 1)).c_str());
+	for (int i = 0; i < 8; ++i) c.radius_coef[i] = num(k, ("radius_" + std::to_string(i + 1) + "_coef").c_str());
+	return c;
+}
+
+void BatchController::init(const std::map<std::string, std::string>& keys, unsigned control_period_ms, int device, int precision)
+{
+	if (control_period_ms == 0 || control_period_ms > 4) throw std::runtime_error("Invalid control period."); // VTMControlModelConfiguration.cpp:38
+	config_ = config_from_keys(keys, precision);
+	const double control_rate = 1000.0 / control_period_ms;
+	if (gvtm_plan_create(&config_, control_rate, device, &plan_) != GVTM_OK) throw std::runtime_error(gvtm_last_error());
+}
+
+BatchController::BatchController(const std::string& voice_dir, int device, int precision)
+{
+	const std::string dir = (!voice_dir.empty() && voice_dir.back() == '/') ? voice_dir : voice_dir + '/';
+	const auto index = read_key_value_file(dir + "_index.txt");
+	auto entry = [&](const char* key) {
+		auto it = index.find(key);
+		if (it == index.end()) throw std::runtime_error(std::string("Key '") + key + "' not found in " + dir + "_index.txt");
+		return dir + it->second;
+	};
+	auto keys = read_key_value_file(entry("vtm_file"));
+	const auto control = read_key_value_file(entry("vtm_control_model_file"));
+	auto vn = control.find("variant_name");
+	if (vn == control.end()) throw std::runtime_error("Key 'variant_name' not found.");
+	for (const auto& kv : read_key_value_file(entry("variant_dir") + vn->second + ".txt")) keys[kv.first] = kv.second; // insert(): overwrite
+	init(keys, static_cast<unsigned>(num(control, "control_period")), device, precision);
+}
+
+BatchController::BatchController(const std::map<std::string, std::string>& merged_keys, unsigned control_period_ms, int device, int precision)
+{
+	init(merged_keys, control_period_ms, device, precision);
+}
+
+BatchController::~BatchController()
+{
+	gvtm_plan_destroy(plan_);
+}
+
+double BatchController::internalSampleRate() const
+{
+	gvtm_info info{};
+	gvtm_plan_info(plan_, &info);
+	return info.internal_sample_rate;
+}
+
+std::size_t BatchController::addUtteranceFromStream(std::istream& in)
+{
+	std::vector<float> frames;
+	std::string line;
+	unsigned line_no = 1;
+	while (std::getline(in, line)) {
+		std::istringstream ls(line);
+		float v[GVTM_N_PARAM];
+		for (float& x : v) ls >> x;
+		if (!ls) {
+			throw std::runtime_error("Could not read vocal tract parameters from stream (line number " + std::to_string(line_no) + ").");
+		}
+		frames.insert(frames.end(), v, v + GVTM_N_PARAM);
+		++line_no;
+	}
+	return addUtterance(std::move(frames));
+}
+
+std::size_t BatchController::addUtterance(std::vector<float> frames)
+{
+	if (frames.size() % GVTM_N_PARAM != 0) throw std::runtime_error("parameter frames must hold 16 values each");
+	utterances_.push_back(std::move(frames));
+	return utterances_.size() - 1;
+}
+
+void BatchController::synthesize()
+{
+	const std::size_t batch = utterances_.size();
+	if (batch == 0) return;
+	std::size_t max_frames = 0;
+	std::vector<int32_t> frames(batch);
+	for (std::size_t b = 0; b < batch; ++b) {
+		frames[b] = static_cast<int32_t>(utterances_[b].size() / GVTM_N_PARAM);
+		max_frames = std::max<std::size_t>(max_frames, static_cast<std::size_t>(frames[b]));
+	}
+	std::vector<float> params(batch * max_frames * GVTM_N_PARAM, 0.0f);
+	for (std::size_t b = 0; b < batch; ++b) {
+		std::copy(utterances_[b].begin(), utterances_[b].end(), params.begin() + static_cast<std::ptrdiff_t>(b * max_frames * GVTM_N_PARAM));
+	}
+	stride_ = gvtm_output_count(plan_, max_frames);
+	if (stride_ == static_cast<std::size_t>(-1)) throw std::runtime_error(gvtm_last_error());
+	audio_.assign(batch * stride_, 0.0f);
+	counts_.assign(batch, 0);
+	maxabs_.assign(batch, 0.0f);
+	const int rc = gvtm_synthesize_batch_host(plan_, params.data(), frames.data(), batch, max_frames, audio_.data(), stride_,
+			counts_.data(), maxabs_.data());
+	if (rc != GVTM_OK) throw std::runtime_error(std::string("synthesis failed: ") + gvtm_last_error());
+}
+
+const float* BatchController::samples(std::size_t i) const { return audio_.data() + i * stride_; }
+std::size_t BatchController::sampleCount(std::size_t i) const { return static_cast<std::size_t>(counts_.at(i)); }
+
+float BatchController::outputScale(std::size_t i) const
+{
+	const float peak = maxabs_.at(i);
+	return peak < 1.0e-30f ? 0.0f : 0.95f / peak;
+}
+
+std::vector<float> BatchController::scaledBuffer(std::size_t i) const
+{
+	const float scale = outputScale(i);
+	std::vector<float> out(sampleCount(i));
+	const float* x = samples(i);
+	for (std::size_t n = 0; n < out.size(); ++n) out[n] = x[n] * scale;
+	return out;
+}
+
+void BatchController::writeWav(std::size_t i, const std::string& path) const
+{
+	FILE* f = std::fopen(path.c_str(), "wb");
+	if (!f) throw std::runtime_error("Could not open the file " + path + " for writing.");
+	auto u32 = [&](int v) { const unsigned char a[4] = {static_cast<unsigned char>(v & 0xff), static_cast<unsigned char>((v >> 8) & 0xff),
+			static_cast<unsigned char>((v >> 16) & 0xff), static_cast<unsigned char>((v >> 24) & 0xff)}; std::fwrite(a, 1, 4, f); };
+	auto u16 = [&](int v) { const unsigned char a[2] = {static_cast<unsigned char>(v & 0xff), static_cast<unsigned char>((v >> 8) & 0xff)}; std::fwrite(a, 1, 2, f); };
+	// header fields as WAVEFileWriter::writeWaveFileHeader (WAVEFileWriter.cpp:62-118), mono 16-bit PCM
+	const int n = static_cast<int>(sampleCount(i));
+	const int data_bytes = n * 2;
+	const float rate = static_cast<float>(config_.output_rate);
+	std::fputs("RIFF", f); u32(4 + 24 + (8 + data_bytes)); std::fputs("WAVE", f);
+	std::fputs("fmt ", f); u32(16); u16(1); u16(1);
+	u32(static_cast<int>(std::round(rate))); u32(static_cast<int>(std::ceil(rate * 2))); u16(2); u16(16);
+	std::fputs("data", f); u32(data_bytes);
+	const float scale = outputScale(i);
+	const float* x = samples(i);
+	for (int s = 0; s < n; ++s) u16(static_cast<int>(std::round((x[s] * scale) * 32767.0f))); // writeSample, WAVEFileWriter.cpp:122-125
+	std::fclose(f);
+}
+
+} // namespace gvtm

@@ -1,0 +1,69 @@
+// Batched counterpart of the VTM-driving half of GS::VTMControlModel::Controller
+// (gama_tts/src/vtm_control_model/Controller.{h,cpp}): it takes the same inputs — a voice
+// directory (or a merged key=value configuration) and parameter streams with one 16-float
+// frame per line — and produces what Controller::synthesizeToFile / synthesizeToBuffer produce,
+// for many utterances at once, through the C ABI of libgama_vtm.so.
+#pragma once
+
+#include <cstdint>
+#include <iosfwd>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gama_vtm.h"
+
+namespace gvtm {
+
+// key = value file, '#' comments at line start (ConfigurationData.cpp:67-118 format).
+std::map<std::string, std::string> read_key_value_file(const std::string& path);
+
+// vtm.txt keys (merged with the variant) -> gvtm_config.  `model` selects the semantics:
+// 0, 2 -> SectionDelay 1; 3 -> SectionDelay 3 (VocalTractModel.cpp:40-47); others are refused.
+gvtm_config config_from_keys(const std::map<std::string, std::string>& keys, int precision);
+
+class BatchController {
+public:
+	// Loads <voice_dir>/_index.txt, the vtm file, the control-model file (control_period,
+	// variant_name) and the variant, merged the way Controller's constructor does
+	// (Controller.cpp:40-55, VTMControlModelConfiguration.cpp:32-60).
+	BatchController(const std::string& voice_dir, int device, int precision = GVTM_PRECISION_F64);
+	// From an already merged configuration and an explicit control period in ms (1..4).
+	BatchController(const std::map<std::string, std::string>& merged_keys, unsigned control_period_ms, int device,
+			int precision = GVTM_PRECISION_F64);
+	~BatchController();
+	BatchController(const BatchController&) = delete;
+	BatchController& operator=(const BatchController&) = delete;
+
+	// One frame per line, 16 whitespace-separated floats (Controller::getParametersFromStream,
+	// Controller.cpp:170-192).  Returns the utterance index.
+	std::size_t addUtteranceFromStream(std::istream& in);
+	std::size_t addUtterance(std::vector<float> frames /* [n][16] */);
+	std::size_t size() const { return utterances_.size(); }
+
+	// Controller::synthesize + finishSynthesis for every queued utterance (one device launch).
+	void synthesize();
+
+	double outputSampleRate() const { return config_.output_rate; }
+	double internalSampleRate() const;
+	// Unscaled samples of utterance i (VocalTractModel::outputBuffer()).
+	const float* samples(std::size_t i) const;
+	std::size_t sampleCount(std::size_t i) const;
+	// Util::calculateOutputScale: 0.95 / max|x|, 0 below 1e-30 (VTMUtil.cpp:48-67).
+	float outputScale(std::size_t i) const;
+	// Controller::writeOutputToBuffer (Controller.cpp:330-340).
+	std::vector<float> scaledBuffer(std::size_t i) const;
+	// Controller::writeOutputToFile (Controller.cpp:315-328): 16-bit mono RIFF/WAVE.
+	void writeWav(std::size_t i, const std::string& path) const;
+private:
+	void init(const std::map<std::string, std::string>& keys, unsigned control_period_ms, int device, int precision);
+	gvtm_config config_{};
+	gvtm_plan* plan_ = nullptr;
+	std::vector<std::vector<float>> utterances_;
+	std::vector<float> audio_;
+	std::vector<int64_t> counts_;
+	std::vector<float> maxabs_;
+	std::size_t stride_ = 0;
+};
+
+} // namespace gvtm

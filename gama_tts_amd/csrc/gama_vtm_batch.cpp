@@ -1,0 +1,58 @@
+// gama_vtm_batch — batched form of `gama_tts vtm` (gama_tts/src/main.cpp:286-337):
+//
+//   gama_vtm_batch [-d device] [-m] <voice_dir> <out_dir> <param_file>...
+//
+// Every parameter file holds one utterance (one 16-float frame per line, the format written
+// by `gama_tts tts -p`); all of them are synthesized in one device launch and written as
+// <out_dir>/<basename>.wav, scaled like Controller::writeOutputToFile.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "batch_controller.hpp"
+
+int main(int argc, char** argv)
+{
+	int device = 0;
+	int precision = GVTM_PRECISION_F64;
+	int i = 1;
+	for (; i < argc && argv[i][0] == '-'; ++i) {
+		if (std::strcmp(argv[i], "-d") == 0 && i + 1 < argc) device = std::atoi(argv[++i]);
+		else if (std::strcmp(argv[i], "-m") == 0) precision = GVTM_PRECISION_MIXED;
+		else { std::cerr << "unknown option " << argv[i] << std::endl; return EXIT_FAILURE; }
+	}
+	if (argc - i < 3) {
+		std::cerr << "usage: " << argv[0] << " [-d device] [-m] voice_dir out_dir param_file..." << std::endl;
+		return EXIT_FAILURE;
+	}
+	try {
+		gvtm::BatchController controller(argv[i], device, precision);
+		const std::string out_dir = argv[i + 1];
+		std::vector<std::string> names;
+		for (int a = i + 2; a < argc; ++a) {
+			std::ifstream in(argv[a], std::ios_base::binary);
+			if (!in) { std::cerr << "Could not open the file " << argv[a] << '.' << std::endl; return EXIT_FAILURE; }
+			controller.addUtteranceFromStream(in);
+			std::string base = argv[a];
+			const auto slash = base.find_last_of('/');
+			if (slash != std::string::npos) base = base.substr(slash + 1);
+			const auto dot = base.find_last_of('.');
+			if (dot != std::string::npos) base = base.substr(0, dot);
+			names.push_back(base);
+		}
+		controller.synthesize();
+		for (std::size_t u = 0; u < controller.size(); ++u) {
+			const std::string path = out_dir + "/" + names[u] + ".wav";
+			controller.writeWav(u, path);
+			std::printf("%s: %zu samples, scale %.6g\n", path.c_str(), controller.sampleCount(u), controller.outputScale(u));
+		}
+	} catch (const std::exception& e) {
+		std::cerr << "Exception: " << e.what() << std::endl;
+		return EXIT_FAILURE;
+	}
+	return EXIT_SUCCESS;
+}

@@ -67,6 +67,8 @@ struct gvtm_plan {
 	DeviceBuffer s_params, s_frames, s_audio, s_counts, s_maxabs;
 	// kernel timing (HIP events on the launch stream)
 	bool timing = false;
+	double* debug_taps = nullptr; // device pointer, see gvtm_debug_set_taps
+	unsigned long long* phase_cycles = nullptr; // device pointer, see gvtm_debug_set_phase_cycles
 	std::vector<EventPair> pending;
 	std::vector<EventPair> pool;
 };
@@ -225,6 +227,24 @@ size_t gvtm_output_count(const gvtm_plan* plan, size_t n_frames)
 	return static_cast<size_t>(n);
 }
 
+/* Test hook (not in the public header): device buffer [batch][max_frames*control_steps][8] of
+ * doubles that receives per-step intermediate values of the next synthesis calls; null disables. */
+int gvtm_debug_set_taps(gvtm_plan* plan, double* d_taps)
+{
+	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
+	plan->debug_taps = d_taps;
+	return GVTM_OK;
+}
+
+/* Diagnostic hook (not in the public header): device buffer [batch][8] of uint64 receiving the
+ * shader cycles workgroup `b` spent in each phase (P1, P2, P3, P4a, P4b, P5, P6, carry). */
+int gvtm_debug_set_phase_cycles(gvtm_plan* plan, unsigned long long* d_cycles)
+{
+	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
+	plan->phase_cycles = d_cycles;
+	return GVTM_OK;
+}
+
 int gvtm_plan_set_timing(gvtm_plan* plan, int enabled)
 {
 	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
@@ -286,6 +306,8 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	args.src_dh = plan->d_src_dh;
 	args.max_frames = max_frames;
 	args.audio_stride = audio_stride;
+	args.debug_taps = plan->debug_taps;
+	args.phase_cycles = plan->phase_cycles;
 
 	EventPair ev;
 	if (plan->timing) {

@@ -84,6 +84,31 @@ __device__ __forceinline__ double amplitude_60db_dev(double db)
 	return exp10((db - 60.0) * (1.0 / 20.0));
 }
 
+// NoiseSource::getSample (vtm/NoiseSource.h:40-44): seed = frac(seed * 377).  The sequence is
+// chaotic, so the product has to be rounded to double before the integer part is removed,
+// exactly as the reference does — a contracted fma(seed, 377, -floor(p)) decorrelates the
+// sequence within a few steps (SURVEY.md hard part 5).
+__device__ __forceinline__ double noise_advance(double seed)
+{
+#pragma clang fp contract(off)
+	const double product = seed * 377.0;
+	return product - floor(product);
+}
+
+// One step of Controller::synthesize's float32 running sum (Controller.cpp:308-310); kept
+// out of FMA contraction so that the per-step parameter values are bit-exact.
+__device__ __forceinline__ float interp_delta(float next, float cur, float coef)
+{
+#pragma clang fp contract(off)
+	const float diff = next - cur;
+	return diff * coef;
+}
+__device__ __forceinline__ float interp_advance(float cur, float delta)
+{
+#pragma clang fp contract(off)
+	return cur + delta;
+}
+
 template <typename TT>
 struct SrcTap {
 	TT h, dh;
@@ -100,25 +125,25 @@ constexpr int kRec = 32;
 constexpr int kRecTap = 16;
 constexpr int kRecU = 24, kRecSig = 25, kRecThr = 26, kRecB0 = 27, kRecA1 = 28, kRecA2 = 29, kRecAlr = 30, kRecAu = 31;
 
-template <typename TT>
+template <typename TT, typename ST>
 struct Smem {
 	double* wavetable; // [512]
 	double* fir;       // [kMaxFirTaps]
-	SrcTap<TT>* src;   // [3328]
+	SrcTap<ST>* src;   // [3328]
 	float* prm;        // [kChunk][16]
 	TT* rec;           // [kChunk][kRec]
 	double* inc;       // [kChunk]
 	double* pos;       // [2*kChunk]
 	double* noise;     // [kChunk]
 	TT* w;             // [kMaxFirTaps + 2*kChunk]
-	TT* x;             // [kXCap]
+	ST* x;             // [kXCap]
 	float* red;        // [kBlock] reduction scratch
 };
 
-template <typename TT>
-__device__ __forceinline__ Smem<TT> carve(unsigned char* base)
+template <typename TT, typename ST>
+__device__ __forceinline__ Smem<TT, ST> carve(unsigned char* base)
 {
-	Smem<TT> s;
+	Smem<TT, ST> s;
 	size_t off = 0;
 	auto take = [&](size_t bytes) {
 		unsigned char* p = base + off;
@@ -127,14 +152,14 @@ __device__ __forceinline__ Smem<TT> carve(unsigned char* base)
 	};
 	s.wavetable = reinterpret_cast<double*>(take(sizeof(double) * kWavetableLength));
 	s.fir = reinterpret_cast<double*>(take(sizeof(double) * kMaxFirTaps));
-	s.src = reinterpret_cast<SrcTap<TT>*>(take(sizeof(SrcTap<TT>) * kSrcFilterLength));
+	s.src = reinterpret_cast<SrcTap<ST>*>(take(sizeof(SrcTap<ST>) * kSrcFilterLength));
 	s.prm = reinterpret_cast<float*>(take(sizeof(float) * kChunk * 16));
 	s.rec = reinterpret_cast<TT*>(take(sizeof(TT) * kChunk * kRec));
 	s.inc = reinterpret_cast<double*>(take(sizeof(double) * kChunk));
 	s.pos = reinterpret_cast<double*>(take(sizeof(double) * 2 * kChunk));
 	s.noise = reinterpret_cast<double*>(take(sizeof(double) * kChunk));
 	s.w = reinterpret_cast<TT*>(take(sizeof(TT) * (kMaxFirTaps + 2 * kChunk)));
-	s.x = reinterpret_cast<TT*>(take(sizeof(TT) * kXCap));
+	s.x = reinterpret_cast<ST*>(take(sizeof(ST) * kXCap));
 	s.red = reinterpret_cast<float*>(take(sizeof(float) * kBlock));
 	return s;
 }
@@ -159,27 +184,28 @@ __device__ __forceinline__ double wavetable_entry(const double* table, const Dev
 size_t synth_lds_bytes(bool mixed)
 {
 	auto al = [](size_t b) { return (b + 15) & ~size_t(15); };
-	const size_t tt = mixed ? sizeof(float) : sizeof(double);
+	const size_t tt = sizeof(double);
+	const size_t st = mixed ? sizeof(float) : sizeof(double);
 	size_t n = 0;
 	n += al(sizeof(double) * kWavetableLength);
 	n += al(sizeof(double) * kMaxFirTaps);
-	n += al(2 * tt * kSrcFilterLength);
+	n += al(2 * st * kSrcFilterLength);
 	n += al(sizeof(float) * kChunk * 16);
 	n += al(tt * kChunk * kRec);
 	n += al(sizeof(double) * kChunk);
 	n += al(sizeof(double) * 2 * kChunk);
 	n += al(sizeof(double) * kChunk);
 	n += al(tt * (kMaxFirTaps + 2 * kChunk));
-	n += al(tt * kXCap);
+	n += al(st * kXCap);
 	n += al(sizeof(float) * kBlock);
 	return n;
 }
 
-template <typename TT, int D>
+template <typename TT, typename ST, int D>
 __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	const Smem<TT> sm = carve<TT>(smem_raw);
+	const Smem<TT, ST> sm = carve<TT, ST>(smem_raw);
 	const DeviceConstants& k = a.k;
 
 	const int tid = threadIdx.x;
@@ -199,11 +225,11 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 	for (int i = tid; i < kWavetableLength; i += kBlock) sm.wavetable[i] = a.wavetable[i];
 	for (int i = tid; i < kMaxFirTaps; i += kBlock) sm.fir[i] = i < taps ? a.fir[i] : 0.0;
 	for (int i = tid; i < kSrcFilterLength; i += kBlock) {
-		sm.src[i].h = static_cast<TT>(a.src_h[i]);
-		sm.src[i].dh = static_cast<TT>(a.src_dh[i]);
+		sm.src[i].h = static_cast<ST>(a.src_h[i]);
+		sm.src[i].dh = static_cast<ST>(a.src_dh[i]);
 	}
 	for (int i = tid; i < kMaxFirTaps + 2 * kChunk; i += kBlock) sm.w[i] = TT(0);
-	for (int i = tid; i < kXCap; i += kBlock) sm.x[i] = TT(0);
+	for (int i = tid; i < kXCap; i += kBlock) sm.x[i] = ST(0);
 
 	// ---- persistent per-role state
 	// P1: lanes 0..15 of wave 0 interpolate parameter `tid`
@@ -243,6 +269,14 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 	const uint64_t n_chunks = steps == 0 ? 1 : (steps + kChunk - 1) / kChunk;
 	__syncthreads();
 
+	// diagnostics: shader cycles per phase, accumulated by thread 0 right after each barrier
+	unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long ph_prev = 0;
+	const bool stamping = a.phase_cycles != nullptr && tid == 0;
+	if (stamping) ph_prev = clock64();
+#define GVTM_STAMP(i) \
+	if (stamping) { const unsigned long long now_ = clock64(); ph_acc[i] += now_ - ph_prev; ph_prev = now_; }
+
 	for (uint64_t c = 0; c < n_chunks; ++c) {
 		const uint64_t n0 = c * kChunk;
 		const int valid = static_cast<int>((steps - n0) < static_cast<uint64_t>(kChunk) ? (steps - n0) : kChunk);
@@ -254,11 +288,10 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 				if (ip_j == 0) {
 					// Controller.cpp:297-300: restart from the frame value, delta towards the next frame
 					ip_cur = ip_this;
-					const float diff = ip_next - ip_cur;
-					ip_delta = diff * k.interp_coef;
+					ip_delta = interp_delta(ip_next, ip_cur, k.interp_coef);
 				}
 				sm.prm[s * 16 + tid] = ip_cur;
-				ip_cur = ip_cur + ip_delta; // Controller.cpp:308-310
+				ip_cur = interp_advance(ip_cur, ip_delta); // Controller.cpp:308-310
 				if (++ip_j == k.control_steps) {
 					ip_j = 0;
 					++ip_frame;
@@ -270,6 +303,8 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 			}
 		}
 		__syncthreads();
+
+		GVTM_STAMP(0)
 
 		// ---------------- P2: per-step parameter conversion ----------------
 		if (tid < valid) {
@@ -344,6 +379,8 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 		}
 		__syncthreads();
 
+		GVTM_STAMP(1)
+
 		// ---------------- P3: serial scalar recurrences ----------------
 		if (tid == 64) {
 			for (int s = 0; s < valid; ++s) {
@@ -355,16 +392,15 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 					sc_pos = p;
 					sm.pos[2 * s + h] = p;
 				}
-				// NoiseSource::getSample: seed = frac(seed * 377) — the product must round
-				// before the fractional part is taken (no fused multiply-subtract).
-				const double product = __dmul_rn(sc_seed, 377.0);
-				sc_seed = product - floor(product);
+				sc_seed = noise_advance(sc_seed);
 				const double white = sc_seed - 0.5;
 				sm.noise[s] = white + sc_prev; // NoiseFilter::filter
 				sc_prev = white;
 			}
 		}
 		__syncthreads();
+
+		GVTM_STAMP(2)
 
 		// ---------------- P4a: wavetable lookups at the 2x oversampled rate ----------------
 		for (int h = tid; h < 2 * valid; h += kBlock) {
@@ -378,6 +414,8 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 			sm.w[hist_w + h] = static_cast<TT>(wl + ((p - static_cast<double>(lower)) * (wu - wl)));
 		}
 		__syncthreads();
+
+		GVTM_STAMP(3)
 
 		// ---------------- P4b: FIR decimator + source mixing ----------------
 		if (tid < valid) {
@@ -401,8 +439,15 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 			rec[kRecU] = static_cast<TT>((pulse + (ah1 * signal)) * 0.125);
 			rec[kRecSig] = static_cast<TT>(signal);
 			rec[kRecThr] = static_cast<TT>(pulse * 0.125);
+			if (a.debug_taps) {
+				double* t = a.debug_taps + (utt * a.max_frames * k.control_steps + n0 + tid) * 8;
+				t[0] = rec[kRecU]; t[1] = rec[kRecSig]; t[2] = rec[kRecThr]; t[3] = acc; t[4] = lp;
+				t[5] = sm.pos[2 * tid]; t[6] = sm.pos[2 * tid + 1];
+			}
 		}
 		__syncthreads();
+
+		GVTM_STAMP(4)
 
 		// ---------------- P5: the waveguide, one section per lane ----------------
 		if (wave == 0) {
@@ -454,43 +499,48 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 						sample += ty * thr_gain;
 						top[ph] = tn;
 						bot[ph] = bn;
-						if (lane == 0) sm.x[hist_x + s] = sample;
+						if (lane == 0) {
+							sm.x[hist_x + s] = static_cast<ST>(sample);
+							if (a.debug_taps) a.debug_taps[(utt * a.max_frames * k.control_steps + n0 + s) * 8 + 7] = sample;
+						}
 					}
 				}
 			}
 			if (last) {
 				// flushBuffer (SampleRateConverter.h:462-471): 2*pad zero samples follow the utterance
-				for (int i = lane; i < 2 * k.pad; i += 64) sm.x[hist_x + valid + i] = TT(0);
+				for (int i = lane; i < 2 * k.pad; i += 64) sm.x[hist_x + valid + i] = ST(0);
 			}
 		}
 		__syncthreads();
+
+		GVTM_STAMP(5)
 
 		// ---------------- P6: sample-rate conversion, one lane per output sample ----------------
 		{
 			const uint64_t filled = last ? steps + 2ull * k.pad : n0 + kChunk;
 			const uint64_t k_end = ((filled << 16) + k.time_inc - 1) / k.time_inc; // outputs with P_k < filled
-			const TT* xb = sm.x + hist_x - static_cast<int64_t>(n0); // xb[n] = internal sample n
+			const ST* xb = sm.x + hist_x - static_cast<int64_t>(n0); // xb[n] = internal sample n
 			for (uint64_t ko = k_next + tid; ko < k_end; ko += kBlock) {
 				const uint64_t t = ko * k.time_inc;
 				const int64_t Pk = static_cast<int64_t>(t >> 16);
 				const unsigned frac = static_cast<unsigned>(t & 0xFFFFu);
 				// ring index p of the reference holds internal sample p - pad
-				const TT* v = xb + (Pk - k.pad);
-				TT acc = 0;
+				const ST* v = xb + (Pk - k.pad);
+				ST acc = 0;
 				if (k.upsampling) {
 					const unsigned l = frac >> 8, m = frac & 0xFFu;
-					const TT interp = static_cast<TT>(m) / TT(256);
+					const ST interp = static_cast<ST>(m) / ST(256);
 #pragma unroll
 					for (int j = 0; j < kSrcZeroCrossings; ++j) {
-						const SrcTap<TT> c = sm.src[l + 256 * j];
+						const SrcTap<ST> c = sm.src[l + 256 * j];
 						acc += v[-j] * (c.h + (c.dh * interp));
 					}
 					const unsigned nfrac = (~frac) & 0xFFFFu;
 					const unsigned l2 = nfrac >> 8, m2 = nfrac & 0xFFu;
-					const TT interp2 = static_cast<TT>(m2) / TT(256);
+					const ST interp2 = static_cast<ST>(m2) / ST(256);
 #pragma unroll
 					for (int j = 0; j < kSrcZeroCrossings; ++j) {
-						const SrcTap<TT> c = sm.src[l2 + 256 * j];
+						const SrcTap<ST> c = sm.src[l2 + 256 * j];
 						acc += v[1 + j] * (c.h + (c.dh * interp2));
 					}
 				} else {
@@ -498,16 +548,16 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 					unsigned ii;
 					int j = 0;
 					while ((ii = (ph >> 8)) < static_cast<unsigned>(kSrcFilterLength)) {
-						const SrcTap<TT> c = sm.src[ii];
-						acc += v[-j] * (c.h + (c.dh * (static_cast<TT>(ph & 0xFFu) / TT(256))));
+						const SrcTap<ST> c = sm.src[ii];
+						acc += v[-j] * (c.h + (c.dh * (static_cast<ST>(ph & 0xFFu) / ST(256))));
 						++j;
 						ph += k.phase_inc;
 					}
 					ph = static_cast<unsigned>(rint(static_cast<double>((~frac) & 0xFFFFu) * k.src_ratio));
 					j = 0;
 					while ((ii = (ph >> 8)) < static_cast<unsigned>(kSrcFilterLength)) {
-						const SrcTap<TT> c = sm.src[ii];
-						acc += v[1 + j] * (c.h + (c.dh * (static_cast<TT>(ph & 0xFFu) / TT(256))));
+						const SrcTap<ST> c = sm.src[ii];
+						acc += v[1 + j] * (c.h + (c.dh * (static_cast<ST>(ph & 0xFFu) / ST(256))));
 						++j;
 						ph += k.phase_inc;
 					}
@@ -520,6 +570,8 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 		}
 		__syncthreads();
 
+		GVTM_STAMP(6)
+
 		// ---------------- carry histories into the next chunk ----------------
 		if (!last) {
 			for (int i = tid; i < hist_x; i += kBlock) sm.x[i] = sm.x[kChunk + i];
@@ -529,6 +581,12 @@ __global__ __launch_bounds__(kBlock) void vtm_synth_kernel(const SynthArgs a)
 			__syncthreads();
 			if (tid < hist_w) sm.w[tid] = keep;
 		}
+	}
+
+	GVTM_STAMP(7)
+#undef GVTM_STAMP
+	if (stamping) {
+		for (int i = 0; i < 8; ++i) a.phase_cycles[utt * 8 + i] = ph_acc[i];
 	}
 
 	// ---- per-utterance peak (for Util::calculateOutputScale) and sample count
@@ -560,14 +618,14 @@ __global__ __launch_bounds__(256) void vtm_normalize_kernel(const NormalizeArgs 
 			i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
 		const float v = in[i] * scale;
 		if (a.out_f32) a.out_f32[utt * a.audio_stride + i] = v;
-		if (a.out_i16) a.out_i16[utt * a.audio_stride + i] = static_cast<int16_t>(rintf(v * 32767.0f));
+		if (a.out_i16) a.out_i16[utt * a.audio_stride + i] = static_cast<int16_t>(static_cast<int>(roundf(v * 32767.0f)));
 	}
 }
 
-template <typename TT, int D>
+template <typename TT, typename ST, int D>
 static hipError_t launch_one(const SynthArgs& args, size_t batch, size_t lds, hipStream_t stream)
 {
-	auto fn = vtm_synth_kernel<TT, D>;
+	auto fn = vtm_synth_kernel<TT, ST, D>;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
 	if (e != hipSuccess) return e;
@@ -581,17 +639,17 @@ hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, hipStre
 	const int d = args.k.section_delay;
 	if (mixed) {
 		switch (d) {
-		case 1: return launch_one<float, 1>(args, batch, lds, stream);
-		case 2: return launch_one<float, 2>(args, batch, lds, stream);
-		case 3: return launch_one<float, 3>(args, batch, lds, stream);
-		case 4: return launch_one<float, 4>(args, batch, lds, stream);
+		case 1: return launch_one<double, float, 1>(args, batch, lds, stream);
+		case 2: return launch_one<double, float, 2>(args, batch, lds, stream);
+		case 3: return launch_one<double, float, 3>(args, batch, lds, stream);
+		case 4: return launch_one<double, float, 4>(args, batch, lds, stream);
 		}
 	} else {
 		switch (d) {
-		case 1: return launch_one<double, 1>(args, batch, lds, stream);
-		case 2: return launch_one<double, 2>(args, batch, lds, stream);
-		case 3: return launch_one<double, 3>(args, batch, lds, stream);
-		case 4: return launch_one<double, 4>(args, batch, lds, stream);
+		case 1: return launch_one<double, double, 1>(args, batch, lds, stream);
+		case 2: return launch_one<double, double, 2>(args, batch, lds, stream);
+		case 3: return launch_one<double, double, 3>(args, batch, lds, stream);
+		case 4: return launch_one<double, double, 4>(args, batch, lds, stream);
 		}
 	}
 	return hipErrorInvalidValue;

@@ -27,6 +27,8 @@ struct SynthArgs {
 	const double* src_dh;        // [3328]
 	size_t max_frames;
 	size_t audio_stride;
+	double* debug_taps;          // null, or [batch][max_frames*control_steps][8] per-step taps (tests only)
+	unsigned long long* phase_cycles; // null, or [batch][8] shader cycles spent per phase (diagnostics only)
 };
 
 struct NormalizeArgs {

@@ -1,0 +1,204 @@
+// libgama_vtm_plugin.so — GamaTTS VocalTractModel plugin over the C ABI of libgama_vtm.so.
+// See include/gama_vtm_plugin.h for the contract.  Host-side C++ only; all synthesis happens
+// in gvtm_synthesize_batch_host().
+#include <cstdio>
+#include <cstdlib>
+#include <exception>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/gama_vtm.h"
+#include "../../include/gama_vtm_plugin.h"
+
+namespace {
+
+// Layout mirror of GS::ConfigurationData (gama_tts/src/ConfigurationData.h:58-65).
+struct ConfigurationDataMirror {
+	std::string filePath;
+	std::string dirPath;
+	std::unordered_map<std::string, std::string> valueMap;
+};
+
+// Same virtual-function order as GS::VTM::VocalTractModel (vtm/VocalTractModel.h:46-59).
+class VocalTractModelAbi {
+public:
+	virtual ~VocalTractModelAbi() noexcept = default;
+	virtual void reset() noexcept = 0;
+	virtual double internalSampleRate() const noexcept = 0;
+	virtual double outputSampleRate() const noexcept = 0;
+	virtual void setParameter(int parameter, float value) noexcept = 0;
+	virtual void setAllParameters(const std::vector<float>& parameters) noexcept = 0;
+	virtual void execSynthesisStep() noexcept = 0;
+	virtual void finishSynthesis() noexcept = 0;
+	virtual std::vector<float>& outputBuffer() noexcept = 0;
+};
+
+class KeyReader {
+public:
+	explicit KeyReader(const ConfigurationDataMirror& d) : d_(d) {}
+	// Same conversions as ConfigurationData::convertString<double/int> (ConfigurationData.cpp:122-166).
+	double number(const char* key) const
+	{
+		auto it = d_.valueMap.find(key);
+		if (it == d_.valueMap.end()) throw std::runtime_error(std::string("Key '") + key + "' not found in " + d_.filePath);
+		return std::stod(it->second);
+	}
+	int integer(const char* key) const
+	{
+		auto it = d_.valueMap.find(key);
+		if (it == d_.valueMap.end()) throw std::runtime_error(std::string("Key '") + key + "' not found in " + d_.filePath);
+		return std::stoi(it->second);
+	}
+	std::string text(const char* key, const char* fallback) const
+	{
+		auto it = d_.valueMap.find(key);
+		return it == d_.valueMap.end() ? std::string(fallback) : it->second;
+	}
+	bool has(const char* key) const { return d_.valueMap.count(key) != 0; }
+private:
+	const ConfigurationDataMirror& d_;
+};
+
+class DeviceVocalTractModel final : public VocalTractModelAbi {
+public:
+	explicit DeviceVocalTractModel(const ConfigurationDataMirror& data)
+	{
+		const KeyReader k(data);
+		gvtm_config c{};
+		c.output_rate = k.number("output_rate");
+		c.waveform = k.integer("waveform");
+		c.noise_modulation = k.integer("noise_modulation");
+		c.glottal_pulse_tp = k.number("glottal_pulse_tp");
+		c.glottal_pulse_tn_min = k.number("glottal_pulse_tn_min");
+		c.glottal_pulse_tn_max = k.number("glottal_pulse_tn_max");
+		c.breathiness = k.number("breathiness");
+		c.vocal_tract_length_offset = k.number("vocal_tract_length_offset");
+		c.vocal_tract_length = k.number("vocal_tract_length");
+		c.temperature = k.number("temperature");
+		c.loss_factor = k.number("loss_factor");
+		c.mouth_coefficient = k.number("mouth_coefficient");
+		c.nose_coefficient = k.number("nose_coefficient");
+		c.throat_cutoff = k.number("throat_cutoff");
+		c.throat_volume = k.number("throat_volume");
+		c.mix_offset = k.number("mix_offset");
+		c.global_radius_coef = k.number("global_radius_coef");
+		c.global_nasal_radius_coef = k.number("global_nasal_radius_coef");
+		c.aperture_radius = k.number("aperture_radius");
+		static const char* const nasal_keys[5] = {"nasal_radius_1", "nasal_radius_2", "nasal_radius_3", "nasal_radius_4", "nasal_radius_5"};
+		static const char* const coef_keys[8] = {"radius_1_coef", "radius_2_coef", "radius_3_coef", "radius_4_coef",
+				"radius_5_coef", "radius_6_coef", "radius_7_coef", "radius_8_coef"};
+		for (int i = 0; i < 5; ++i) c.nasal_radius[i] = k.number(nasal_keys[i]);
+		for (int i = 0; i < 8; ++i) c.radius_coef[i] = k.number(coef_keys[i]);
+		c.section_delay = k.has("section_delay") ? k.integer("section_delay") : 1;
+		c.precision = k.text("gpu_precision", "f64") == "mixed" ? GVTM_PRECISION_MIXED : GVTM_PRECISION_F64;
+		const int device = k.has("gpu_device") ? k.integer("gpu_device") : 0;
+
+		// The host interpolates the control frames itself (Controller.cpp:294-311) and hands over
+		// one parameter vector per internal step, so the plan runs with one step per "frame":
+		// control rate == internal sample rate.
+		gvtm_plan* probe = nullptr;
+		if (gvtm_plan_create(&c, 1000.0, GVTM_DEVICE_NONE, &probe) != GVTM_OK) throw std::runtime_error(gvtm_last_error());
+		gvtm_info info{};
+		gvtm_plan_info(probe, &info);
+		gvtm_plan_destroy(probe);
+		internal_rate_ = info.internal_sample_rate;
+		output_rate_ = c.output_rate;
+		if (gvtm_plan_create(&c, static_cast<double>(info.internal_sample_rate), device, &plan_) != GVTM_OK) {
+			throw std::runtime_error(gvtm_last_error());
+		}
+		gvtm_plan_info(plan_, &info);
+		if (info.control_steps != 1) throw std::runtime_error("internal error: plugin plan must run one step per frame");
+		current_.assign(GVTM_N_PARAM, 0.0f);
+		output_.reserve(1024);
+	}
+	~DeviceVocalTractModel() noexcept override { gvtm_plan_destroy(plan_); }
+
+	void reset() noexcept override
+	{
+		steps_.clear();
+		output_.clear();
+	}
+	double internalSampleRate() const noexcept override { return internal_rate_; }
+	double outputSampleRate() const noexcept override { return output_rate_; }
+	void setParameter(int parameter, float value) noexcept override
+	{
+		if (parameter < 0 || parameter >= GVTM_N_PARAM) return; // fail silently, VocalTractModel0.h:690-692
+		current_[static_cast<std::size_t>(parameter)] = value;
+	}
+	void setAllParameters(const std::vector<float>& parameters) noexcept override
+	{
+		if (parameters.size() != GVTM_N_PARAM) return; // fail silently, VocalTractModel0.h:700-703
+		current_ = parameters;
+	}
+	void execSynthesisStep() noexcept override
+	{
+		try {
+			steps_.insert(steps_.end(), current_.begin(), current_.end());
+		} catch (...) {
+			failed_ = true;
+		}
+	}
+	void finishSynthesis() noexcept override
+	{
+		try {
+			const std::size_t n_steps = steps_.size() / GVTM_N_PARAM;
+			const std::size_t n_out = gvtm_output_count(plan_, n_steps);
+			if (failed_ || n_out == static_cast<std::size_t>(-1)) {
+				std::fprintf(stderr, "[gama_vtm_plugin] cannot synthesize: %s\n", failed_ ? "out of memory while recording" : gvtm_last_error());
+				output_.clear();
+				return;
+			}
+			output_.assign(n_out, 0.0f);
+			int64_t written = 0;
+			const int rc = gvtm_synthesize_batch_host(plan_, steps_.data(), nullptr, 1, n_steps, output_.data(), n_out, &written, nullptr);
+			if (rc != GVTM_OK) {
+				std::fprintf(stderr, "[gama_vtm_plugin] synthesis failed: %s\n", gvtm_last_error());
+				output_.clear();
+				return;
+			}
+			output_.resize(static_cast<std::size_t>(written));
+			steps_.clear();
+		} catch (...) {
+			output_.clear();
+		}
+	}
+	std::vector<float>& outputBuffer() noexcept override { return output_; }
+private:
+	gvtm_plan* plan_ = nullptr;
+	double internal_rate_ = 0.0;
+	double output_rate_ = 0.0;
+	bool failed_ = false;
+	std::vector<float> current_;
+	std::vector<float> steps_;  // [n_steps][16], as handed over by the host
+	std::vector<float> output_;
+};
+
+} // namespace
+
+extern "C" {
+
+void* GAMA_TTS_construct_vocal_tract_model(const void* config_data, int is_interactive)
+{
+	if (!config_data) return nullptr;
+	if (is_interactive) {
+		std::fprintf(stderr, "[gama_vtm_plugin] interactive (per-step polled) use is not served by the device backend\n");
+		return nullptr;
+	}
+	try {
+		return static_cast<VocalTractModelAbi*>(new DeviceVocalTractModel(*static_cast<const ConfigurationDataMirror*>(config_data)));
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "[gama_vtm_plugin] construct failed: %s\n", e.what());
+	} catch (...) {
+		std::fprintf(stderr, "[gama_vtm_plugin] construct failed\n");
+	}
+	return nullptr;
+}
+
+void GAMA_TTS_destruct_vocal_tract_model(void* vtm)
+{
+	delete static_cast<VocalTractModelAbi*>(vtm);
+}
+
+} // extern "C"

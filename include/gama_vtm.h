@@ -55,7 +55,7 @@ typedef enum gvtm_status {
 /* Arithmetic the device path computes in. */
 typedef enum gvtm_precision {
 	GVTM_PRECISION_F64 = 0,  /* everything in fp64, like VocalTractModel0<double> */
-	GVTM_PRECISION_MIXED = 1 /* fp64 oscillator phase / noise / design tables, fp32 tube, filters, FIR, SRC */
+	GVTM_PRECISION_MIXED = 1 /* fp64 sources, tube and filters; fp32 sample-rate converter (tables, window, MACs) */
 } gvtm_precision;
 
 /* The configuration keys VocalTractModel0/2::loadConfiguration reads from the merged

@@ -1,0 +1,48 @@
+/*
+ * gama_vtm_plugin.h — the GamaTTS VocalTractModel plugin boundary served by
+ * libgama_vtm_plugin.so.
+ *
+ * GamaTTS loads a vocal-tract model with `model = 2000` + `dll_path = <this .so>` in vtm.txt
+ * (gama_tts/src/vtm/VocalTractModel.cpp:52-55, built with -DGAMATTS_ENABLE_VTM_PLUGINS=ON).
+ * Its loader resolves exactly the two symbols below (vtm/VocalTractModelPlugin.cpp:40-50,
+ * :76-85) and treats the returned pointer as a `GS::VTM::VocalTractModel*`
+ * (vtm/VocalTractModelPlugin.cpp:87), i.e. the object must have the Itanium-ABI vtable
+ *
+ *     ~VocalTractModel() (two slots), reset(), internalSampleRate(), outputSampleRate(),
+ *     setParameter(int, float), setAllParameters(const std::vector<float>&),
+ *     execSynthesisStep(), finishSynthesis(), outputBuffer() -> std::vector<float>&
+ *
+ * in this order (vtm/VocalTractModel.h:46-59).  `config_data` is the host's
+ * `const GS::ConfigurationData*` (two std::string members followed by a
+ * std::unordered_map<std::string, std::string>, ConfigurationData.h:58-65); the plugin reads the
+ * key/value map through a layout-compatible mirror and therefore has to be built with the
+ * same libstdc++ (_GLIBCXX_USE_CXX11_ABI=1) as the host.
+ *
+ * Behaviour
+ *   - Batch protocol only: parameters are recorded per execSynthesisStep() and the whole
+ *     utterance is synthesized on the GPU inside finishSynthesis() (Controller reads
+ *     outputBuffer() only after finishSynthesis(), Controller.cpp:226-235).
+ *   - `is_interactive != 0` (the editor's per-step polling of outputBuffer()) cannot be served
+ *     by a deferred device backend: construct returns NULL, which the host reports as
+ *     "Could not construct the vocal tract model." (VocalTractModelPlugin.cpp:88-90).
+ *   - No exception crosses the C boundary; any failure inside construct returns NULL and
+ *     writes the reason to stderr.
+ *   - Optional extra keys in vtm.txt: `gpu_device` (int, default 0), `gpu_precision`
+ *     ("f64" default | "mixed"), `section_delay` (1..4, default 1: VocalTractModel0 semantics;
+ *     3 reproduces model 3).
+ */
+#ifndef GAMA_VTM_PLUGIN_H_
+#define GAMA_VTM_PLUGIN_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void* GAMA_TTS_construct_vocal_tract_model(const void* config_data, int is_interactive);
+void GAMA_TTS_destruct_vocal_tract_model(void* vtm);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* GAMA_VTM_PLUGIN_H_ */

@@ -171,6 +171,7 @@ typedef struct {
 	int taps, ptr;
 	double coef[VTMO_FIR_MAX_TAPS];
 	double data[VTMO_FIR_MAX_TAPS];
+	double* tap_pos; /* optional debug tap */
 } glottal_source;
 
 /* ctor, WavetableGlottalSource.h:90-141 */
@@ -261,6 +262,7 @@ static double glottal_sample(glottal_source* g, double freq)
 	double output = 0.0;
 	for (int i = 0; i < 2; ++i) {
 		g->position = mod0(g->position + ((freq / 2.0) * g->basic_increment));
+		if (g->tap_pos) g->tap_pos[i] = g->position;
 		const unsigned lower = (unsigned) (long long) g->position;
 		const unsigned upper = (unsigned) (long long) mod0((double) (lower + 1));
 		const double v = g->table[lower] + ((g->position - lower) * (g->table[upper] - g->table[lower]));
@@ -553,6 +555,7 @@ typedef struct {
 	glottal_source glottal;
 	double noise_seed, noise_x1;
 	src_state src;
+	double* taps; /* optional debug taps for the current step: u, sig, thr, fir, lpnoise, pos0, pos1, x */
 } vtm_model;
 
 static double junction2(double left_radius, double right_radius)
@@ -740,7 +743,9 @@ static double model_step(vtm_model* m)
 	m->noise_x1 = white;
 
 	if (m->waveform == 0) glottal_setup(&m->glottal, ax);
+	m->glottal.tap_pos = m->taps ? m->taps + 5 : NULL;
 	double pulse = glottal_sample(&m->glottal, f0);
+	if (m->taps) { m->taps[3] = pulse; m->taps[4] = lp_noise; }
 	const double pulsed_noise = lp_noise * pulse;
 	pulse = ax * ((pulse * (1.0 - m->breathiness_factor)) + (pulsed_noise * m->breathiness_factor));
 
@@ -753,8 +758,10 @@ static double model_step(vtm_model* m)
 		signal = lp_noise;
 	}
 	const double fric = bandpass_run(&m->bandpass, signal);
+	if (m->taps) { m->taps[0] = (pulse + (ah1 * signal)) * 0.125; m->taps[1] = signal; m->taps[2] = pulse * 0.125; }
 	signal = model_vocal_tract(m, ((pulse + (ah1 * signal)) * 0.125), fric);
 	signal += throat_run(&m->throat, pulse * 0.125);
+	if (m->taps) m->taps[7] = signal;
 	return signal;
 }
 
@@ -793,7 +800,7 @@ void vtmo_noise_sequence(double* lp_noise, size_t count)
 }
 
 static size_t run(const vtmo_config* cfg, double control_rate, const float* params, size_t n_frames,
-		float* out, size_t cap, double* internal_signal, int count_only)
+		float* out, size_t cap, double* internal_signal, int count_only, double* taps)
 {
 	vtm_model* m = (vtm_model*) malloc(sizeof(vtm_model));
 	if (!m) return (size_t) -1;
@@ -820,6 +827,7 @@ static size_t run(const vtmo_config* cfg, double control_rate, const float* para
 					src_data_fill(&m->src, 0.0);
 				} else {
 					model_set_parameters(m, cur);
+					m->taps = taps ? taps + step * 8 : NULL;
 					const double s = model_step(m);
 					if (internal_signal) internal_signal[step] = s;
 					src_data_fill(&m->src, s);
@@ -836,13 +844,13 @@ static size_t run(const vtmo_config* cfg, double control_rate, const float* para
 
 size_t vtmo_output_count(const vtmo_config* cfg, double control_rate, size_t n_frames)
 {
-	return run(cfg, control_rate, NULL, n_frames, NULL, 0, NULL, 1);
+	return run(cfg, control_rate, NULL, n_frames, NULL, 0, NULL, 1, NULL);
 }
 
 size_t vtmo_synthesize(const vtmo_config* cfg, double control_rate, const float* params, size_t n_frames,
 		float* out, size_t out_capacity, double* internal_signal)
 {
-	return run(cfg, control_rate, params, n_frames, out, out_capacity, internal_signal, 0);
+	return run(cfg, control_rate, params, n_frames, out, out_capacity, internal_signal, 0, NULL);
 }
 
 size_t vtmo_synthesize_batch(const vtmo_config* cfg, double control_rate, const float* params,
@@ -851,8 +859,16 @@ size_t vtmo_synthesize_batch(const vtmo_config* cfg, double control_rate, const 
 	size_t n = 0;
 	for (size_t b = 0; b < batch; ++b) {
 		n = run(cfg, control_rate, params + b * n_frames * VTMO_N_PARAM, n_frames,
-				out + b * out_stride, out_stride, NULL, 0);
+				out + b * out_stride, out_stride, NULL, 0, NULL);
 		if (n == (size_t) -1) return n;
 	}
 	return n;
+}
+
+/* Debug: per-step taps[n_steps][8] = tube input, band-pass input, throat input, FIR output,
+ * low-passed noise, oscillator position after each half step (2), sample handed to the SRC. */
+size_t vtmo_synthesize_debug(const vtmo_config* cfg, double control_rate, const float* params, size_t n_frames,
+		float* out, size_t out_capacity, double* taps)
+{
+	return run(cfg, control_rate, params, n_frames, out, out_capacity, NULL, 0, taps);
 }

@@ -96,6 +96,12 @@ size_t vtmo_synthesize(const vtmo_config* cfg, double control_rate,
 		const float* params, size_t n_frames,
 		float* out, size_t out_capacity, double* internal_signal);
 
+/* Debug variant: taps[n_frames*control_steps][8] receives, per internal step: tube input,
+ * band-pass input, throat input, glottal FIR output, low-passed noise, oscillator position
+ * after each of the two half steps, sample handed to the SRC. */
+size_t vtmo_synthesize_debug(const vtmo_config* cfg, double control_rate,
+		const float* params, size_t n_frames, float* out, size_t out_capacity, double* taps);
+
 /* Batch of equal-length utterances, params[batch][n_frames][16],
  * out[batch][out_stride]; returns samples per utterance. */
 size_t vtmo_synthesize_batch(const vtmo_config* cfg, double control_rate,

@@ -125,6 +125,9 @@ def lib():
         L.vtmo_synthesize_batch.argtypes = [P(OracleConfig), ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
         L.vtmo_synthesize_batch.restype = ctypes.c_size_t
+        L.vtmo_synthesize_debug.argtypes = [P(OracleConfig), ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.vtmo_synthesize_debug.restype = ctypes.c_size_t
         L.vtmo_output_scale.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         L.vtmo_output_scale.restype = ctypes.c_float
         _lib = L
@@ -159,6 +162,18 @@ def synthesize(cfg, params, control_rate=250.0, want_internal=False):
                                 out.ctypes.data, n, ip)
     assert got == n, (got, n)
     return (out, internal) if want_internal else out
+
+
+def synthesize_debug(cfg, params, control_rate=250.0):
+    """-> (audio, taps float64 [steps][8]); tap layout in oracle/vtm_oracle.h."""
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    frames = params.shape[0]
+    n = output_count(cfg, frames, control_rate)
+    out = np.empty(n, dtype=np.float32)
+    taps = np.zeros((frames * derive(cfg, control_rate).control_steps, 8), dtype=np.float64)
+    lib().vtmo_synthesize_debug(ctypes.byref(cfg), control_rate, params.ctypes.data, frames, out.ctypes.data, n,
+                                taps.ctypes.data)
+    return out, taps
 
 
 def synthesize_batch(cfg, params, control_rate=250.0):

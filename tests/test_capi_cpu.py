@@ -101,3 +101,19 @@ def test_no_cpu_synthesis_path():
         with pytest.raises(g.GvtmError) as ei:
             g.Plan(g.config_from_dict(d), 250.0, 0)
         assert ei.value.status == 2
+
+
+def test_plugin_library_exports_the_gamatts_symbols():
+    libdir = os.path.dirname(g.library_path())
+    g.load_library()  # libgama_vtm.so first: the plugin links against it
+    plugin = ctypes.CDLL(os.path.join(libdir, "libgama_vtm_plugin.so"))
+    for name in _declared_symbols("gama_vtm_plugin.h"):
+        assert hasattr(plugin, name), name
+    plugin.GAMA_TTS_construct_vocal_tract_model.restype = ctypes.c_void_p
+    plugin.GAMA_TTS_construct_vocal_tract_model.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    # interactive use (per-step polling) is refused: NULL -> the host raises
+    # "Could not construct the vocal tract model." (VocalTractModelPlugin.cpp:88-90)
+    dummy = ctypes.create_string_buffer(256)
+    assert plugin.GAMA_TTS_construct_vocal_tract_model(dummy, 1) is None
+    assert plugin.GAMA_TTS_construct_vocal_tract_model(None, 0) is None
+    assert os.access(os.path.join(libdir, "gama_vtm_batch"), os.X_OK)

@@ -1,0 +1,92 @@
+"""Drop-in boundary on the GPU: the GamaTTS plugin loaded by the REAL reference loader, and
+the batched `gama_tts vtm` counterpart (C++ host over the C ABI)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import gama_tts_amd as g
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+LIBDIR = os.path.join(os.path.dirname(g.library_path()))
+PLUGIN = os.path.join(LIBDIR, "libgama_vtm_plugin.so")
+CLI = os.path.join(LIBDIR, "gama_vtm_batch")
+
+
+@pytest.mark.skipif(oracle.ref_binary() is None, reason="oracle/_ref/ref_vtm (the compiled reference) not present")
+@pytest.mark.parametrize("name", ["hello_m0", "rand5_m0"])
+def test_plugin_through_reference_loader(name, golden, tmp_path):
+    """ref_vtm is the reference's own VocalTractModel::getInstance + VocalTractModelPlugin
+    (dlopen/dlsym, vtm/VocalTractModelPlugin.cpp:57-91) driven by Controller::synthesize's loop;
+    with model = 2000 every virtual call lands in our plugin object."""
+    import golden_cases
+    case = next(c for c in golden_cases.CASES if c["name"] == name)
+    tr = golden_cases.track_for(case, golden)
+    out, info = oracle.ref_synthesize(tr, "2000:" + PLUGIN, tmpdir=str(tmp_path))
+    ref = golden[name + "__out"]
+    assert out.size == ref.size == int(info["N"])
+    assert float(info["fs"]) == 20034.0
+    err = np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err <= 1e-9, err
+
+
+def _make_voice_dir(root):
+    keys = oracle.read_config_file(oracle.VOICE_MALE)
+    os.makedirs(os.path.join(root, "variant"))
+    variant_keys = ("vocal_tract_length", "glottal_pulse_tp", "glottal_pulse_tn_min", "glottal_pulse_tn_max",
+                    "reference_glottal_pitch", "breathiness", "aperture_radius", "intonation_factor")
+    with open(os.path.join(root, "_index.txt"), "w") as f:
+        f.write("variant_dir = variant/\nvtm_control_model_file = vtm_control_model.txt\nvtm_file = vtm.txt\n")
+    with open(os.path.join(root, "vtm.txt"), "w") as f:
+        f.write("# test voice\n")
+        for k, v in keys.items():
+            if k not in variant_keys:
+                f.write("%s = %s\n" % (k, v))
+    with open(os.path.join(root, "variant", "male.txt"), "w") as f:
+        for k in variant_keys:
+            f.write("%s = %s\n" % (k, keys[k]))
+    with open(os.path.join(root, "vtm_control_model.txt"), "w") as f:
+        f.write("control_period = 4\nvariant_name = male\n")
+
+
+def _read_wav(path):
+    data = open(path, "rb").read()
+    assert data[:4] == b"RIFF" and data[8:16] == b"WAVEfmt "
+    fmt = struct.unpack("<IHHIIHH", data[16:36])
+    assert data[36:40] == b"data"
+    n = struct.unpack("<I", data[40:44])[0]
+    return fmt, np.frombuffer(data[44:44 + n], dtype="<i2")
+
+
+def test_batched_vtm_cli_writes_reference_wavs(golden, tmp_path):
+    """`gama_vtm_batch voice_dir out_dir a.txt b.txt` == `gama_tts vtm` per file: same frames in,
+    same 16-bit samples out (scale 0.95/max, round(x * 32767), WAVEFileWriter.cpp:62-125)."""
+    voice = str(tmp_path / "voice")
+    _make_voice_dir(voice)
+    out_dir = str(tmp_path / "out")
+    os.makedirs(out_dir)
+    tracks_ = {"hello": np.asarray(golden["hello_params"]), "short": np.asarray(golden["hello_params"])[:40]}
+    files = []
+    for name, tr in tracks_.items():
+        p = str(tmp_path / (name + ".txt"))
+        with open(p, "w") as f:
+            for row in tr:
+                f.write(" ".join("%.9g" % v for v in row) + "\n")
+        files.append(p)
+    r = subprocess.run([CLI, voice, out_dir] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cfg = oracle.male_config()
+    for name, tr in tracks_.items():
+        fmt, pcm = _read_wav(os.path.join(out_dir, name + ".wav"))
+        assert fmt == (16, 1, 1, 44100, 88200, 2, 16)
+        ref = oracle.synthesize(cfg, tr)
+        assert pcm.size == ref.size
+        scaled = (ref * np.float32(oracle.output_scale(ref))) * np.float32(32767.0)
+        want = (np.sign(scaled) * np.floor(np.abs(scaled) + np.float32(0.5))).astype(np.int32)
+        assert np.abs(pcm.astype(np.int32) - want).max() <= 1
+        assert np.mean(pcm.astype(np.int32) == want) > 0.999
+    assert np.abs(_read_wav(os.path.join(out_dir, "hello.wav"))[1]).max() == 31129  # round(0.95 * 32767)
