@@ -3,6 +3,7 @@
 // plugin convention: construct returns nullptr, VocalTractModelPlugin.cpp:87-90).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -59,10 +60,12 @@ struct gvtm_plan {
 	gvtm::Design design;
 	int device = 0;
 	bool mixed = false;
+	int generation = 2; // kernel generation; GVTM_KERNEL=1 selects the round-1 baseline for A/B runs
 	double* d_wavetable = nullptr;
 	double* d_fir = nullptr;
 	double* d_src_h = nullptr;
 	double* d_src_dh = nullptr;
+	gvtm::DeviceConstants* d_consts = nullptr;
 	// staging for the host-buffer entry point
 	DeviceBuffer s_params, s_frames, s_audio, s_counts, s_maxabs;
 	// kernel timing (HIP events on the launch stream)
@@ -95,6 +98,7 @@ void free_plan(gvtm_plan* p)
 	if (p->d_fir) (void) hipFree(p->d_fir);
 	if (p->d_src_h) (void) hipFree(p->d_src_h);
 	if (p->d_src_dh) (void) hipFree(p->d_src_dh);
+	if (p->d_consts) (void) hipFree(p->d_consts);
 	p->s_params.release();
 	p->s_frames.release();
 	p->s_audio.release();
@@ -143,6 +147,7 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 		const std::string why = gvtm::design_plan(*config, control_rate, plan->design);
 		if (!why.empty()) return fail(GVTM_ERR_INVALID_ARGUMENT, why);
 		plan->mixed = config->precision == GVTM_PRECISION_MIXED;
+		if (const char* gen = std::getenv("GVTM_KERNEL")) plan->generation = (gen[0] == '1') ? 1 : 2;
 
 		if (device == GVTM_DEVICE_NONE) {
 			// design-only plan: info, tables and output counts work, synthesis reports NO_DEVICE
@@ -167,6 +172,7 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 		if ((e = upload(&plan->d_fir, plan->design.fir)) != hipSuccess) return fail_hip(e, "upload fir");
 		if ((e = upload(&plan->d_src_h, plan->design.src_h)) != hipSuccess) return fail_hip(e, "upload src_h");
 		if ((e = upload(&plan->d_src_dh, plan->design.src_dh)) != hipSuccess) return fail_hip(e, "upload src_dh");
+		if ((e = upload(&plan->d_consts, std::vector<gvtm::DeviceConstants>(1, plan->design.k))) != hipSuccess) return fail_hip(e, "upload constants");
 		*plan_out = plan.release();
 		return GVTM_OK;
 	} catch (const std::bad_alloc&) {
@@ -245,6 +251,22 @@ int gvtm_debug_set_phase_cycles(gvtm_plan* plan, unsigned long long* d_cycles)
 	return GVTM_OK;
 }
 
+/* Diagnostic hook: what each lane receives through the cross-lane primitives of the tube
+ * wavefront (row_shr:1, row_shl:1, row_ror:6, row_ror:10); out[4][64] host ints. */
+int gvtm_debug_dpp_selftest(gvtm_plan* plan, int* out)
+{
+	if (!plan || !out || plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_INVALID_ARGUMENT, "needs a device plan");
+	hipError_t e = hipSetDevice(plan->device);
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	int* d = nullptr;
+	if ((e = hipMalloc(reinterpret_cast<void**>(&d), 256 * sizeof(int))) != hipSuccess) return fail_hip(e, "hipMalloc");
+	e = gvtm::launch_dpp_selftest(d, nullptr);
+	if (e == hipSuccess) e = hipMemcpy(out, d, 256 * sizeof(int), hipMemcpyDeviceToHost);
+	(void) hipFree(d);
+	if (e != hipSuccess) return fail_hip(e, "dpp selftest");
+	return GVTM_OK;
+}
+
 int gvtm_plan_set_timing(gvtm_plan* plan, int enabled)
 {
 	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
@@ -287,7 +309,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	if (audio_stride < need) {
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
 	}
-	if (gvtm::synth_lds_bytes(plan->mixed) > 160 * 1024) return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
+	if (gvtm::synth_lds_bytes(plan->mixed, plan->generation) > 160 * 1024) return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
 
 	hipError_t e = hipSetDevice(plan->device);
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -295,6 +317,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 
 	gvtm::SynthArgs args;
 	args.k = plan->design.k;
+	args.kconst = plan->d_consts;
 	args.params = d_params;
 	args.frame_counts = d_frame_counts;
 	args.audio = d_audio;
@@ -306,6 +329,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	args.src_dh = plan->d_src_dh;
 	args.max_frames = max_frames;
 	args.audio_stride = audio_stride;
+	args.batch = batch;
 	args.debug_taps = plan->debug_taps;
 	args.phase_cycles = plan->phase_cycles;
 
@@ -320,7 +344,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 		}
 		if ((e = hipEventRecord(ev.start, stream)) != hipSuccess) return fail_hip(e, "hipEventRecord");
 	}
-	e = gvtm::launch_synth(args, batch, plan->mixed, stream);
+	e = gvtm::launch_synth(args, batch, plan->mixed, plan->generation, stream);
 	if (plan->timing) {
 		(void) hipEventRecord(ev.stop, stream);
 		plan->pending.push_back(ev);

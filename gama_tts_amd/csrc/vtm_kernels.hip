@@ -40,6 +40,7 @@ namespace {
 } // namespace
 
 #include "vtm_kernel_v1.inc"
+#include "vtm_kernel_v2.inc"
 
 // Controller::writeOutputToBuffer / writeOutputToFile (Controller.cpp:315-340): scale by
 // 0.95 / max|x| (Util::calculateOutputScale, VTMUtil.cpp:48-67); the int16 form rounds as
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void vtm_normalize_kernel(const NormalizeArgs 
 }
 
 template <typename TT, typename ST, int D>
-static hipError_t launch_one(const SynthArgs& args, size_t batch, size_t lds, hipStream_t stream)
+static hipError_t launch_v1(const SynthArgs& args, size_t batch, size_t lds, hipStream_t stream)
 {
 	auto fn = v1::vtm_synth_kernel<TT, ST, D>;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -72,28 +73,79 @@ static hipError_t launch_one(const SynthArgs& args, size_t batch, size_t lds, hi
 	return hipGetLastError();
 }
 
-size_t synth_lds_bytes(bool mixed)
+// generation-2 geometry: utterances per workgroup (DPP rows), chunk length, helper wavefronts,
+// internal-rate ring length
+template <bool MIXED, int U_>
+struct V2Shape {
+	static constexpr int U = U_;
+	static constexpr int C = (U_ == 1) ? 48 : 24;
+	static constexpr int NH = 4;
+	static constexpr int XR = 512;
+};
+
+template <typename ST, int D, int U>
+static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
-	return v1::synth_lds_bytes(mixed);
+	using S = V2Shape<sizeof(ST) == 4, U>;
+	auto fn = v2::vtm_synth_kernel<ST, D, S::U, S::C, S::NH, S::XR>;
+	const size_t lds = v2::smem_bytes<ST, S::U, S::C, S::XR>();
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+			static_cast<int>(lds));
+	if (e != hipSuccess) return e;
+	const unsigned groups = static_cast<unsigned>((batch + S::U - 1) / S::U);
+	hipLaunchKernelGGL(fn, dim3(groups), dim3((4 + S::NH) * 64), lds, stream, args);
+	return hipGetLastError();
 }
 
-hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, hipStream_t stream)
+hipError_t launch_dpp_selftest(int* d_out, hipStream_t stream)
 {
-	const size_t lds = v1::synth_lds_bytes(mixed);
+	hipLaunchKernelGGL(v2::dpp_selftest_kernel, dim3(1), dim3(64), 0, stream, d_out);
+	return hipGetLastError();
+}
+
+size_t synth_lds_bytes(bool mixed, int generation)
+{
+	if (generation == 1) return v1::synth_lds_bytes(mixed);
+	using SM = V2Shape<true, 1>;
+	using SD = V2Shape<false, 1>;
+	return mixed ? v2::smem_bytes<float, SM::U, SM::C, SM::XR>() : v2::smem_bytes<double, SD::U, SD::C, SD::XR>();
+}
+
+hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, hipStream_t stream)
+{
 	const int d = args.k.section_delay;
+	if (generation == 1) {
+		const size_t lds = v1::synth_lds_bytes(mixed);
+		if (mixed) {
+			switch (d) {
+			case 1: return launch_v1<double, float, 1>(args, batch, lds, stream);
+			case 2: return launch_v1<double, float, 2>(args, batch, lds, stream);
+			case 3: return launch_v1<double, float, 3>(args, batch, lds, stream);
+			case 4: return launch_v1<double, float, 4>(args, batch, lds, stream);
+			}
+		} else {
+			switch (d) {
+			case 1: return launch_v1<double, double, 1>(args, batch, lds, stream);
+			case 2: return launch_v1<double, double, 2>(args, batch, lds, stream);
+			case 3: return launch_v1<double, double, 3>(args, batch, lds, stream);
+			case 4: return launch_v1<double, double, 4>(args, batch, lds, stream);
+			}
+		}
+		return hipErrorInvalidValue;
+	}
 	if (mixed) {
 		switch (d) {
-		case 1: return launch_one<double, float, 1>(args, batch, lds, stream);
-		case 2: return launch_one<double, float, 2>(args, batch, lds, stream);
-		case 3: return launch_one<double, float, 3>(args, batch, lds, stream);
-		case 4: return launch_one<double, float, 4>(args, batch, lds, stream);
+		case 1: return launch_v2<float, 1, 1>(args, batch, stream);
+		case 2: return launch_v2<float, 2, 1>(args, batch, stream);
+		case 3: return launch_v2<float, 3, 1>(args, batch, stream);
+		case 4: return launch_v2<float, 4, 1>(args, batch, stream);
 		}
 	} else {
 		switch (d) {
-		case 1: return launch_one<double, double, 1>(args, batch, lds, stream);
-		case 2: return launch_one<double, double, 2>(args, batch, lds, stream);
-		case 3: return launch_one<double, double, 3>(args, batch, lds, stream);
-		case 4: return launch_one<double, double, 4>(args, batch, lds, stream);
+		case 1: return launch_v2<double, 1, 1>(args, batch, stream);
+		case 2: return launch_v2<double, 2, 1>(args, batch, stream);
+		case 3: return launch_v2<double, 3, 1>(args, batch, stream);
+		case 4: return launch_v2<double, 4, 1>(args, batch, stream);
 		}
 	}
 	return hipErrorInvalidValue;

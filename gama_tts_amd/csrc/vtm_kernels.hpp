@@ -15,7 +15,8 @@ constexpr int kChunk = 192;  // internal-rate steps per chunk; multiple of every
 constexpr int kXCap = (2 * kMaxPad) + kChunk + (2 * kMaxPad); // SRC window: history + chunk + flush zeros
 
 struct SynthArgs {
-	DeviceConstants k;
+	DeviceConstants k;              // by value (generation 1)
+	const DeviceConstants* kconst;  // the same constants in device memory (generation 2 stages them in LDS)
 	const float* params;         // [batch][max_frames][16]
 	const int32_t* frame_counts; // [batch] or null
 	float* audio;                // [batch][audio_stride]
@@ -27,6 +28,7 @@ struct SynthArgs {
 	const double* src_dh;        // [3328]
 	size_t max_frames;
 	size_t audio_stride;
+	size_t batch;
 	double* debug_taps;          // null, or [batch][max_frames*control_steps][8] per-step taps (tests only)
 	unsigned long long* phase_cycles; // null, or [batch][8] shader cycles spent per phase (diagnostics only)
 };
@@ -41,8 +43,10 @@ struct NormalizeArgs {
 	size_t audio_stride;
 };
 
-size_t synth_lds_bytes(bool mixed);
-hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, hipStream_t stream);
+// generation: 1 = phase-alternating baseline, 2 = wave-specialised pipeline (default)
+size_t synth_lds_bytes(bool mixed, int generation);
+hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, hipStream_t stream);
+hipError_t launch_dpp_selftest(int* d_out /* [256] */, hipStream_t stream);
 hipError_t launch_normalize(const NormalizeArgs& args, size_t batch, hipStream_t stream);
 
 } // namespace gvtm
