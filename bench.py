@@ -154,15 +154,22 @@ def main():
     plan.set_timing(False)
     assert int(d_counts.min().item()) == n_out and int(d_counts.max().item()) == n_out
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from gama_tts_amd.shard import max_over_ranks
+    elapsed = max_over_ranks(elapsed, dist, dev)
 
     total_samples = float(n_out) * args.batch * world * args.steps
     value = total_samples / elapsed
     algo_bytes = float(args.batch) * (args.frames * 64.0 + n_out * 4.0)
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+
+    # HBM traffic of this workload as measured with rocprofv3 PMC passes (profiles/traffic.json)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            key = "batch%d_frames%d_delay%d_%s" % (args.batch, args.frames, args.delay, args.precision)
+            traffic = json.load(f).get(key, {}).get("bytes")
+    except (OSError, ValueError):
+        pass
 
     if rank == 0:
         line = {
@@ -196,8 +203,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None,
-                "kernel": "vtm_synth_kernel",
+                "traffic": traffic,
+                "kernel": "gvtm::v2::vtm_synth_kernel" if os.environ.get("GVTM_KERNEL", "2") != "1" else "gvtm::v1::vtm_synth_kernel",
                 "kernel_ms": kernel_ms,
                 "launches_timed": launches,
                 "algorithmic_bytes_per_launch": algo_bytes,

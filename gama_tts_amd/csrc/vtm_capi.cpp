@@ -61,6 +61,7 @@ struct gvtm_plan {
 	int device = 0;
 	bool mixed = false;
 	int generation = 2; // kernel generation; GVTM_KERNEL=1 selects the round-1 baseline for A/B runs
+	int rows = 0;       // utterances per workgroup; 0 = by batch size, GVTM_ROWS=1|2|4 forces it (tests)
 	double* d_wavetable = nullptr;
 	double* d_fir = nullptr;
 	double* d_src_h = nullptr;
@@ -148,6 +149,7 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 		if (!why.empty()) return fail(GVTM_ERR_INVALID_ARGUMENT, why);
 		plan->mixed = config->precision == GVTM_PRECISION_MIXED;
 		if (const char* gen = std::getenv("GVTM_KERNEL")) plan->generation = (gen[0] == '1') ? 1 : 2;
+		if (const char* rows = std::getenv("GVTM_ROWS")) plan->rows = std::atoi(rows);
 
 		if (device == GVTM_DEVICE_NONE) {
 			// design-only plan: info, tables and output counts work, synthesis reports NO_DEVICE
@@ -309,7 +311,8 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	if (audio_stride < need) {
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
 	}
-	if (gvtm::synth_lds_bytes(plan->mixed, plan->generation) > 160 * 1024) return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
+	const int rows = gvtm::synth_rows(plan->mixed, batch, plan->rows);
+	if (gvtm::synth_lds_bytes(plan->mixed, plan->generation, rows) > 160 * 1024) return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
 
 	hipError_t e = hipSetDevice(plan->device);
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -344,7 +347,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 		}
 		if ((e = hipEventRecord(ev.start, stream)) != hipSuccess) return fail_hip(e, "hipEventRecord");
 	}
-	e = gvtm::launch_synth(args, batch, plan->mixed, plan->generation, stream);
+	e = gvtm::launch_synth(args, batch, plan->mixed, plan->generation, rows, stream);
 	if (plan->timing) {
 		(void) hipEventRecord(ev.stop, stream);
 		plan->pending.push_back(ev);

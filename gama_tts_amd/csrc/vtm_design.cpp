@@ -280,7 +280,7 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 	design_wavetable(c, k, out.wavetable);
 	out.fir = design_glottal_fir();
 	k.fir_taps = static_cast<int>(out.fir.size());
-	if (k.fir_taps > kMaxFirTaps) return "glottal FIR longer than the device buffer";
+	if (k.fir_taps > kMaxFirTaps || k.fir_taps > 49) return "glottal FIR longer than the device pre-roll (49 taps)";
 	design_src_filter(out.src_h, out.src_dh);
 	return "";
 }

@@ -78,7 +78,7 @@ static hipError_t launch_v1(const SynthArgs& args, size_t batch, size_t lds, hip
 template <bool MIXED, int U_>
 struct V2Shape {
 	static constexpr int U = U_;
-	static constexpr int C = (U_ == 1) ? 48 : 24;
+	static constexpr int C = (U_ == 1) ? 48 : 24; // 12 divides by every SectionDelay; LDS caps U * C
 	static constexpr int NH = 4;
 	static constexpr int XR = 512;
 };
@@ -103,15 +103,46 @@ hipError_t launch_dpp_selftest(int* d_out, hipStream_t stream)
 	return hipGetLastError();
 }
 
-size_t synth_lds_bytes(bool mixed, int generation)
+int synth_rows(bool mixed, size_t batch, int requested)
 {
-	if (generation == 1) return v1::synth_lds_bytes(mixed);
-	using SM = V2Shape<true, 1>;
-	using SD = V2Shape<false, 1>;
-	return mixed ? v2::smem_bytes<float, SM::U, SM::C, SM::XR>() : v2::smem_bytes<double, SD::U, SD::C, SD::XR>();
+	// utterances per workgroup = DPP rows used by the serial wavefronts.  One row keeps the most
+	// workgroups in flight (best latency for small batches); more rows amortise the serial
+	// instruction streams once there are more utterances than compute units.
+	const int max_rows = mixed ? 4 : 2; // fp64 resampler tables leave LDS for two rows only
+	int rows = requested;
+	if (rows != 1 && rows != 2 && rows != 4) {
+		rows = batch > 512 ? 4 : (batch > 256 ? 2 : 1);
+	}
+	return rows > max_rows ? max_rows : rows;
 }
 
-hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, hipStream_t stream)
+template <typename ST, int U>
+static size_t v2_lds()
+{
+	using S = V2Shape<sizeof(ST) == 4, U>;
+	return v2::smem_bytes<ST, S::U, S::C, S::XR>();
+}
+
+size_t synth_lds_bytes(bool mixed, int generation, int rows)
+{
+	if (generation == 1) return v1::synth_lds_bytes(mixed);
+	if (mixed) return rows == 4 ? v2_lds<float, 4>() : (rows == 2 ? v2_lds<float, 2>() : v2_lds<float, 1>());
+	return rows == 2 ? v2_lds<double, 2>() : v2_lds<double, 1>();
+}
+
+template <typename ST, int U>
+static hipError_t launch_v2_d(const SynthArgs& args, size_t batch, hipStream_t stream)
+{
+	switch (args.k.section_delay) {
+	case 1: return launch_v2<ST, 1, U>(args, batch, stream);
+	case 2: return launch_v2<ST, 2, U>(args, batch, stream);
+	case 3: return launch_v2<ST, 3, U>(args, batch, stream);
+	case 4: return launch_v2<ST, 4, U>(args, batch, stream);
+	}
+	return hipErrorInvalidValue;
+}
+
+hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, int rows, hipStream_t stream)
 {
 	const int d = args.k.section_delay;
 	if (generation == 1) {
@@ -134,21 +165,12 @@ hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int gen
 		return hipErrorInvalidValue;
 	}
 	if (mixed) {
-		switch (d) {
-		case 1: return launch_v2<float, 1, 1>(args, batch, stream);
-		case 2: return launch_v2<float, 2, 1>(args, batch, stream);
-		case 3: return launch_v2<float, 3, 1>(args, batch, stream);
-		case 4: return launch_v2<float, 4, 1>(args, batch, stream);
-		}
-	} else {
-		switch (d) {
-		case 1: return launch_v2<double, 1, 1>(args, batch, stream);
-		case 2: return launch_v2<double, 2, 1>(args, batch, stream);
-		case 3: return launch_v2<double, 3, 1>(args, batch, stream);
-		case 4: return launch_v2<double, 4, 1>(args, batch, stream);
-		}
+		if (rows == 4) return launch_v2_d<float, 4>(args, batch, stream);
+		if (rows == 2) return launch_v2_d<float, 2>(args, batch, stream);
+		return launch_v2_d<float, 1>(args, batch, stream);
 	}
-	return hipErrorInvalidValue;
+	if (rows == 2) return launch_v2_d<double, 2>(args, batch, stream);
+	return launch_v2_d<double, 1>(args, batch, stream);
 }
 
 hipError_t launch_normalize(const NormalizeArgs& args, size_t batch, hipStream_t stream)

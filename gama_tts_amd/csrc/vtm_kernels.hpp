@@ -44,8 +44,11 @@ struct NormalizeArgs {
 };
 
 // generation: 1 = phase-alternating baseline, 2 = wave-specialised pipeline (default)
-size_t synth_lds_bytes(bool mixed, int generation);
-hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, hipStream_t stream);
+// rows: utterances per workgroup for generation 2 (1, 2 or 4); synth_rows() picks it from the
+// batch size unless `requested` names one
+int synth_rows(bool mixed, size_t batch, int requested);
+size_t synth_lds_bytes(bool mixed, int generation, int rows);
+hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, int rows, hipStream_t stream);
 hipError_t launch_dpp_selftest(int* d_out /* [256] */, hipStream_t stream);
 hipError_t launch_normalize(const NormalizeArgs& args, size_t batch, hipStream_t stream);
 

@@ -135,3 +135,22 @@ def test_full_size_properties_config2():
     cfg = oracle.male_config()
     for b in (0, 101, 255):
         assert _peak_err(audio[b], oracle.synthesize(cfg, params[b])) <= TOL_F64
+
+
+@pytest.mark.parametrize("rows,precision,tol", [(2, capi.PRECISION_F64, TOL_F64), (2, capi.PRECISION_MIXED, TOL_MIXED),
+                                                  (4, capi.PRECISION_MIXED, TOL_MIXED)])
+@pytest.mark.parametrize("delay", [1, 3])
+def test_multi_row_workgroups(rows, precision, tol, delay, monkeypatch):
+    """Several utterances per workgroup (one DPP row each in the serial wavefronts), ragged
+    lengths, a batch that does not fill the last workgroup."""
+    monkeypatch.setenv("GVTM_ROWS", str(rows))
+    frames = np.array([40, 0, 17, 33, 40, 1, 25, 40, 8, 39, 40], dtype=np.int32)
+    params = tracks.random_tracks(len(frames), 40, seed0=900 + rows, consonant_heavy=True)
+    plan = _plan(delay=delay, precision=precision)
+    audio, counts, maxabs = plan.synthesize_host(params, frames)
+    cfg = oracle.male_config(44100.0, delay)
+    for b, f in enumerate(frames):
+        ref = oracle.synthesize(cfg, params[b, :f]) if f else np.zeros(oracle.output_count(cfg, 0), np.float32)
+        assert counts[b] == ref.size
+        assert _peak_err(audio[b, : ref.size], ref) <= tol, (b, f)
+        assert maxabs[b] == np.abs(audio[b, : ref.size]).max()
