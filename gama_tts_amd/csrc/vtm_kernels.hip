@@ -79,7 +79,7 @@ template <bool MIXED, int U_>
 struct V2Shape {
 	static constexpr int U = U_;
 	static constexpr int C = (U_ == 1) ? 48 : 24; // 12 divides by every SectionDelay; LDS caps U * C
-	static constexpr int NH = 4;
+	static constexpr int NH = (U_ == 1) ? 3 : 7; // 8 resp. 12 wavefronts per workgroup
 	static constexpr int XR = 512;
 };
 
@@ -93,7 +93,7 @@ static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t str
 			static_cast<int>(lds));
 	if (e != hipSuccess) return e;
 	const unsigned groups = static_cast<unsigned>((batch + S::U - 1) / S::U);
-	hipLaunchKernelGGL(fn, dim3(groups), dim3((4 + S::NH) * 64), lds, stream, args);
+	hipLaunchKernelGGL(fn, dim3(groups), dim3((5 + S::NH) * 64), lds, stream, args);
 	return hipGetLastError();
 }
 

@@ -154,3 +154,19 @@ def test_multi_row_workgroups(rows, precision, tol, delay, monkeypatch):
         assert counts[b] == ref.size
         assert _peak_err(audio[b, : ref.size], ref) <= tol, (b, f)
         assert maxabs[b] == np.abs(audio[b, : ref.size]).max()
+
+
+@pytest.mark.parametrize("frames", [48, 96, 97, 3, 600])
+def test_one_step_per_frame_and_chunk_aligned_lengths(frames):
+    """The plugin's mode of operation (control rate == internal rate, one frame per step) with
+    lengths that are exact multiples of the kernel's chunk: the flush tail must be complete."""
+    d = g.read_config_file(oracle.VOICE_MALE)
+    plan = g.Plan(g.config_from_dict(d, 44100.0, 1), 20034.0, 0)
+    assert plan.info.control_steps == 1
+    params = tracks.random_tracks(2, frames, seed0=4242, consonant_heavy=True)
+    audio, counts, _ = plan.synthesize_host(params)
+    cfg = oracle.male_config()
+    for b in range(2):
+        ref = oracle.synthesize(cfg, params[b], control_rate=20034.0)
+        assert counts[b] == ref.size
+        assert _peak_err(audio[b, : ref.size], ref) <= TOL_F64
