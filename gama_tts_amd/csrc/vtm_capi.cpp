@@ -13,6 +13,7 @@
 #include "../../include/gama_vtm.h"
 #include "vtm_design.hpp"
 #include "vtm_kernels.hpp"
+#include "vtm_math.hpp"
 
 namespace {
 
@@ -244,8 +245,9 @@ int gvtm_debug_set_taps(gvtm_plan* plan, double* d_taps)
 	return GVTM_OK;
 }
 
-/* Diagnostic hook (not in the public header): device buffer [batch][8] of uint64 receiving the
- * shader cycles workgroup `b` spent in each phase (P1, P2, P3, P4a, P4b, P5, P6, carry). */
+/* Diagnostic hook (not in the public header): device buffer [batch][16] of uint64 receiving the
+ * shader cycles workgroup `b` spent per phase (generation 1) or per role wavefront [0..7] and per
+ * helper stage [8..13] (generation 2). */
 int gvtm_debug_set_phase_cycles(gvtm_plan* plan, unsigned long long* d_cycles)
 {
 	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
@@ -266,6 +268,23 @@ int gvtm_debug_dpp_selftest(gvtm_plan* plan, int* out)
 	if (e == hipSuccess) e = hipMemcpy(out, d, 256 * sizeof(int), hipMemcpyDeviceToHost);
 	(void) hipFree(d);
 	if (e != hipSuccess) return fail_hip(e, "dpp selftest");
+	return GVTM_OK;
+}
+
+/* Test hook: the short elementary functions of csrc/vtm_math.hpp evaluated on the host
+ * (kind 0 = 2^x, 1 = 10^x, 2 = cos, 3 = tan). */
+int gvtm_debug_short_math(int kind, const double* x, size_t n, double* out)
+{
+	if (!x || !out) return GVTM_ERR_INVALID_ARGUMENT;
+	for (size_t i = 0; i < n; ++i) {
+		switch (kind) {
+		case 0: out[i] = gvtm::vmath::exp2_short(x[i]); break;
+		case 1: out[i] = gvtm::vmath::exp10_short(x[i]); break;
+		case 2: out[i] = gvtm::vmath::cos_short(x[i]); break;
+		case 3: out[i] = gvtm::vmath::tan_short(x[i]); break;
+		default: return GVTM_ERR_INVALID_ARGUMENT;
+		}
+	}
 	return GVTM_OK;
 }
 

@@ -32,6 +32,7 @@
 
 #include "vtm_design.hpp"
 #include "vtm_kernels.hpp"
+#include "vtm_math.hpp"
 
 namespace gvtm {
 

@@ -24,7 +24,7 @@ n = plan.output_count(frames)
 dev = torch.device("cuda:0")
 d_params = torch.from_numpy(params).to(dev)
 d_audio = torch.zeros((batch, n), dtype=torch.float32, device=dev)
-d_cyc = torch.zeros((batch, 8), dtype=torch.int64, device=dev)
+d_cyc = torch.zeros((batch, 16), dtype=torch.int64, device=dev)
 lib = g.load_library()
 lib.gvtm_debug_set_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 for rep in range(2):

@@ -23,7 +23,7 @@ n = plan.output_count(frames)
 dev = torch.device("cuda:0")
 d_params = torch.from_numpy(params).to(dev)
 d_audio = torch.zeros((batch, n), dtype=torch.float32, device=dev)
-d_cyc = torch.zeros((batch, 8), dtype=torch.int64, device=dev)
+d_cyc = torch.zeros((batch, 16), dtype=torch.int64, device=dev)
 lib = g.load_library()
 lib.gvtm_debug_set_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 for rep in range(2):
@@ -34,8 +34,9 @@ for rep in range(2):
     ms, _ = plan.take_kernel_ms()
 cyc = d_cyc.cpu().numpy().astype(np.float64)
 steps = frames * plan.info.control_steps
-names = ["T tube", "S scan", "F filters", "H0", "H1", "H2", "H3", "H4"]
+names = ["T tube", "S scan", "F1 pre-tube", "F2 post-tube", "I interp", "H0", "H1", "H2",
+         "stage P2a", "stage P2b", "stage P2c", "stage P4a", "stage P4b", "stage P6", "-", "-"]
 print("batch %d frames %d prec %d delay %d: kernel %.3f ms = %.1f ns/step" % (batch, frames, prec, delay, ms, ms * 1e6 / steps))
 for i, nm in enumerate(names):
     if cyc[:, i].max() > 0:
-        print("  %-10s busy %7.1f cycles/step (mean over workgroups; max %.1f)" % (nm, cyc[:, i].mean() / steps, cyc[:, i].max() / steps))
+        print("  %-10s busy %7.1f cycles/step (mean over workgroups; max %.1f)" % (nm, cyc[cyc[:, i] > 0, i].mean() / steps, cyc[:, i].max() / steps))
