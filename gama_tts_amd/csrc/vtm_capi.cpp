@@ -325,6 +325,9 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	if (!d_audio) return fail(GVTM_ERR_INVALID_ARGUMENT, "null audio buffer");
 	if (max_frames > 0 && !d_params) return fail(GVTM_ERR_INVALID_ARGUMENT, "null params with max_frames > 0");
 	if (batch > 0x7fffffffu) return fail(GVTM_ERR_INVALID_ARGUMENT, "batch too large for one launch");
+	if (static_cast<unsigned long long>(max_frames) * plan->design.k.control_steps + 4096ull >= (1ull << 31)) {
+		return fail(GVTM_ERR_INVALID_ARGUMENT, "max_frames * control_steps does not fit the 31-bit step counter");
+	}
 	const size_t need = gvtm_output_count(plan, max_frames);
 	if (need == static_cast<size_t>(-1)) return GVTM_ERR_UNSUPPORTED;
 	if (audio_stride < need) {

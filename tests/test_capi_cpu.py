@@ -140,9 +140,11 @@ def test_short_math_accuracy():
         out = np.empty_like(x)
         assert lib.gvtm_debug_short_math(kind, x.ctypes.data, x.size, out.ctypes.data) == 0
         ref = ref_fn(x.astype(np.longdouble))
-        ok = np.isfinite(ref.astype(np.float64)) & (np.abs(ref) > 1e-3)
+        with np.errstate(over="ignore"):
+            ref64 = ref.astype(np.float64)  # 2^1500 overflows to inf on purpose
+        ok = np.isfinite(ref64) & (np.abs(ref) > 1e-3)
         rel = np.abs((out[ok].astype(np.longdouble) - ref[ok]) / ref[ok])
         assert float(rel.max()) < 4e-16, (kind, float(rel.max()))
-        small = ~ok & np.isfinite(ref.astype(np.float64))
+        small = ~ok & np.isfinite(ref64)
         if small.any():
             assert float(np.abs(out[small].astype(np.longdouble) - ref[small]).max()) < 4e-16
