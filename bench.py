@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--precision", choices=["f64", "mixed"], default="f64")
     ap.add_argument("--output-rate", type=float, default=44100.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,12 +109,17 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the VTM path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     voice = os.path.join(ROOT, "tests", "golden", "voice_male.txt")
     cfgd = g.read_config_file(voice)
@@ -155,7 +162,7 @@ def main():
     assert int(d_counts.min().item()) == n_out and int(d_counts.max().item()) == n_out
 
     from gama_tts_amd.shard import max_over_ranks
-    elapsed = max_over_ranks(elapsed, dist, dev)
+    elapsed = max_over_ranks(elapsed, dist, dev if args.dist_backend == "nccl" else None)
 
     total_samples = float(n_out) * args.batch * world * args.steps
     value = total_samples / elapsed
