@@ -529,6 +529,8 @@ static double bandpass_run(bandpass_filter* f, double x)
 
 enum { S1, S2, S3, S4, S5, S6, S7, S8, S9, S10, N_SECTIONS };
 enum { N1, N2, N3, N4, N5, N6, N_NASAL };
+#define MAX_SECTIONS 30 /* VocalTractModel4: 30 oropharynx + 18 nasal sections */
+#define MAX_NASAL 18
 enum { P_PITCH, P_GLOT_VOL, P_ASP_VOL, P_FRIC_VOL, P_FRIC_POS, P_FRIC_CF, P_FRIC_BW,
        P_R1, P_R2, P_R3, P_R4, P_R5, P_R6, P_R7, P_R8, P_VELUM };
 
@@ -539,12 +541,12 @@ typedef struct {
 	double output_rate, tp, tn_min, tn_max, breathiness, length, temperature, loss_factor;
 	double aperture_radius, mouth_coef, nose_coef, nasal_radius[N_NASAL], throat_cutoff, throat_vol, mix_offset;
 	double radius_coef[8];
-	int waveform, modulation, delay;
+	int waveform, modulation, delay, layout;
 	/* derived (initializeSynthesizer, VocalTractModel0.h:338-392) */
 	int sample_rate;
 	double damping, crossmix_factor, breathiness_factor;
 	/* state */
-	section oro[N_SECTIONS], nasal[N_NASAL];
+	section oro[MAX_SECTIONS], nasal[MAX_NASAL];
 	unsigned in_ptr, out_ptr;
 	double oro_k[8], nasal_k[N_NASAL], alpha_l, alpha_r, alpha_u, tap[8];
 	double cur[VTMO_N_PARAM];
@@ -573,6 +575,8 @@ static int model_init(vtm_model* m, const vtmo_config* c, int count_only)
 	memset(m, 0, sizeof(*m));
 	if (c->section_delay < 1 || c->section_delay > MAX_DELAY) return -1;
 	m->delay = c->section_delay;
+	m->layout = c->layout;
+	if (m->layout != 0 && m->layout != 1) return -1;
 	m->output_rate = c->output_rate;
 	m->waveform = c->waveform;
 	m->tp = c->glottal_pulse_tp;
@@ -600,7 +604,8 @@ static int model_init(vtm_model* m, const vtmo_config* c, int count_only)
 	m->out_ptr = 1;
 
 	const double speed = 331.4 + (0.6 * m->temperature); /* Util::speedOfSound, VTMUtil.h:104-110 */
-	m->sample_rate = (int) ((speed * (N_SECTIONS * m->delay) * 100.0) / m->length);
+	/* TOTAL_SECTIONS is 10 for VocalTractModel0/2 and 30 for VocalTractModel4 (VocalTractModel4.h:467) */
+	m->sample_rate = (int) ((speed * ((m->layout ? MAX_SECTIONS : N_SECTIONS) * m->delay) * 100.0) / m->length);
 	const double nyquist = (float) m->sample_rate / 2.0f; /* int / float -> float arithmetic, VocalTractModel0.h:345 */
 	m->breathiness_factor = m->breathiness / 100.0;
 	m->crossmix_factor = 1.0 / amplitude60dB(m->mix_offset);
@@ -725,6 +730,81 @@ static double model_vocal_tract(vtm_model* m, double input, double frication)
 	return output;
 }
 
+/* Simple copy between sections of one region, VocalTractModel4.h:296-300 */
+static void propagate_copy(vtm_model* m, section* l, section* r)
+{
+	r->top[m->in_ptr] = l->top[m->out_ptr];
+	l->bottom[m->in_ptr] = r->bottom[m->out_ptr];
+}
+
+/* Delay with damping and frication, VocalTractModel4.h:301-305 (== VocalTractModel2.h:251-254) */
+static void propagate_damped(vtm_model* m, section* l, section* r, double fric)
+{
+	r->top[m->in_ptr] = l->top[m->out_ptr] * m->damping + fric;
+	l->bottom[m->in_ptr] = r->bottom[m->out_ptr] * m->damping;
+}
+
+/* vocalTract of VocalTractModel4 (VocalTractModel4.h:671-745): 30 oropharynx + 18 nasal sections,
+ * scattering only at the region boundaries, plain copies inside a region. */
+static double model_vocal_tract4(vtm_model* m, double input, double frication)
+{
+	m->in_ptr = m->out_ptr;
+	m->out_ptr = (m->out_ptr == (unsigned) m->delay) ? 0 : m->out_ptr + 1;
+	const unsigned in = m->in_ptr, out = m->out_ptr;
+	section* o = m->oro; /* o[i] = S(i+1) */
+	section* n = m->nasal;
+	const double d = m->damping;
+	const double* k = m->oro_k; /* J1..J8 */
+	const double* t = m->tap;   /* FC1..FC8 */
+
+	o[0].top[in] = o[0].bottom[out] * d + input;
+	propagate_copy(m, &o[0], &o[1]);
+	propagate_copy(m, &o[1], &o[2]);
+	propagate_junction(m, &o[2], k[0], &o[3], 0.0);
+	propagate_copy(m, &o[3], &o[4]);
+	propagate_junction(m, &o[4], k[1], &o[5], t[0] * frication);
+	propagate_copy(m, &o[5], &o[6]);
+	propagate_copy(m, &o[6], &o[7]);
+	propagate_copy(m, &o[7], &o[8]);
+	propagate_junction(m, &o[8], k[2], &o[9], t[1] * frication);
+	propagate_copy(m, &o[9], &o[10]);
+	propagate_copy(m, &o[10], &o[11]);
+	{ /* 3-way junction S12 / S13 / N1 */
+		const double jp = m->alpha_l * o[11].top[out] + m->alpha_r * o[12].bottom[out] + m->alpha_u * n[0].bottom[out];
+		o[11].bottom[in] = (jp - o[11].top[out]) * d;
+		o[12].top[in] = (jp - o[12].bottom[out]) * d + t[2] * frication;
+		n[0].top[in] = (jp - n[0].bottom[out]) * d;
+	}
+	propagate_copy(m, &o[12], &o[13]);
+	propagate_copy(m, &o[13], &o[14]);
+	propagate_junction(m, &o[14], k[3], &o[15], t[3] * frication);
+	propagate_copy(m, &o[15], &o[16]);
+	propagate_copy(m, &o[16], &o[17]);
+	propagate_damped(m, &o[17], &o[18], t[4] * frication);
+	propagate_copy(m, &o[18], &o[19]);
+	propagate_copy(m, &o[19], &o[20]);
+	propagate_junction(m, &o[20], k[4], &o[21], t[5] * frication);
+	propagate_copy(m, &o[21], &o[22]);
+	propagate_copy(m, &o[22], &o[23]);
+	propagate_copy(m, &o[23], &o[24]);
+	propagate_junction(m, &o[24], k[5], &o[25], t[6] * frication);
+	propagate_copy(m, &o[25], &o[26]);
+	propagate_junction(m, &o[26], k[6], &o[27], t[7] * frication);
+	propagate_copy(m, &o[27], &o[28]);
+	propagate_copy(m, &o[28], &o[29]);
+	o[29].bottom[in] = d * reflection_run(&m->mouth_refl, k[7] * o[29].top[out]);
+	double output = radiation_run(&m->mouth_rad, (1.0 + k[7]) * o[29].top[out]);
+
+	for (int g = 0; g < 6; ++g) { /* nasal regions of three sections, junction after each but the last */
+		propagate_copy(m, &n[3 * g], &n[3 * g + 1]);
+		propagate_copy(m, &n[3 * g + 1], &n[3 * g + 2]);
+		if (g < 5) propagate_junction(m, &n[3 * g + 2], m->nasal_k[g], &n[3 * g + 3], 0.0);
+	}
+	n[17].bottom[in] = d * reflection_run(&m->nose_refl, m->nasal_k[5] * n[17].top[out]);
+	output += radiation_run(&m->nose_rad, (1.0 + m->nasal_k[5]) * n[17].top[out]);
+	return output;
+}
+
 /* execSynthesisStep, VocalTractModel0.h:396-445; returns the sample handed to the SRC */
 static double model_step(vtm_model* m)
 {
@@ -759,7 +839,8 @@ static double model_step(vtm_model* m)
 	}
 	const double fric = bandpass_run(&m->bandpass, signal);
 	if (m->taps) { m->taps[0] = (pulse + (ah1 * signal)) * 0.125; m->taps[1] = signal; m->taps[2] = pulse * 0.125; }
-	signal = model_vocal_tract(m, ((pulse + (ah1 * signal)) * 0.125), fric);
+	signal = m->layout ? model_vocal_tract4(m, ((pulse + (ah1 * signal)) * 0.125), fric)
+	                   : model_vocal_tract(m, ((pulse + (ah1 * signal)) * 0.125), fric);
 	signal += throat_run(&m->throat, pulse * 0.125);
 	if (m->taps) m->taps[7] = signal;
 	return signal;

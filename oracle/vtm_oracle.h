@@ -14,8 +14,8 @@
  *
  * What it restates (reference file:line in vtm_oracle.c next to each function):
  *   Controller::synthesize                      vtm_control_model/Controller.cpp:277-313
- *   VocalTractModel0<double> / VocalTractModel2<double,D>
- *                                               vtm/VocalTractModel0.h, vtm/VocalTractModel2.h
+ *   VocalTractModel0<double> / VocalTractModel2<double,D> / VocalTractModel4<double,D>
+ *                                               vtm/VocalTractModel0.h, vtm/VocalTractModel2.h, vtm/VocalTractModel4.h
  *   WavetableGlottalSource (+FIR), SampleRateConverter, BandpassFilter,
  *   NoiseSource/NoiseFilter, Radiation/ReflectionFilter, Throat, VTMUtil
  */
@@ -58,6 +58,7 @@ typedef struct vtmo_config {
 	double nasal_radius[5];           /* nasal_radius_1..5 (cm) */
 	double radius_coef[8];            /* radius_1_coef..radius_8_coef */
 	int    section_delay;             /* VocalTractModel2's SectionDelay template argument; 1 == VocalTractModel0 */
+	int    layout;                    /* 0: 10 + 6 sections (VocalTractModel0/2); 1: 30 + 18 sections (VocalTractModel4) */
 } vtmo_config;
 
 /* Design-time quantities derived from the configuration. */

@@ -33,8 +33,9 @@ def track_for(case, golden=None):
     return _track(case["track"], golden)
 
 
-def C(name, track, model="0", delay=1, rate=44100.0, crate=250.0, store="full", **ov):
-    return dict(name=name, track=track, model=model, delay=delay, rate=rate, crate=crate, store=store, overrides=ov)
+def C(name, track, model="0", delay=1, rate=44100.0, crate=250.0, store="full", layout=0, **ov):
+    return dict(name=name, track=track, model=model, delay=delay, rate=rate, crate=crate, store=store, layout=layout,
+                overrides=ov)
 
 
 CASES = [
@@ -73,6 +74,15 @@ CASES = [
     C("two_frames_m3", ("random", 120, 5, True, 2), model="3", delay=3),
     C("three_frames", ("random", 120, 5, True, 3)),
     C("thirteen_frames_m3", ("random", 120, 5, True, 13), model="3", delay=3),
+    # VocalTractModel4 (30 + 18 sections, 60102 Hz internal): SURVEY.md section 0 + short tracks
+    C("const_m4", ("const", 500), model="4", layout=1, store="digest"),
+    C("ramp_m4", ("ramp", 500), model="4", layout=1, store="digest"),
+    C("cons2000_m4", ("random", 500, 2000, True), model="4", layout=1, store="digest"),
+    C("hello_m4", ("hello",), model="4", layout=1, store="digest"),
+    C("rand5_m4", ("random", 120, 5, True), model="4", layout=1),
+    C("rand5_m4_48k", ("random", 120, 5, True), model="4", layout=1, rate=48000.0),
+    C("rand6_m4_22k_crate500", ("random", 120, 6, False), model="4", layout=1, rate=22050.0, crate=500.0),
+    C("two_frames_m4", ("random", 120, 5, True, 2), model="4", layout=1),
 ]
 
 DIGEST_STRIDE = 97

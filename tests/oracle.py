@@ -40,6 +40,7 @@ class OracleConfig(ctypes.Structure):
         ("nasal_radius", ctypes.c_double * 5),
         ("radius_coef", ctypes.c_double * 8),
         ("section_delay", ctypes.c_int),
+        ("layout", ctypes.c_int),
     ]
 
 
@@ -71,7 +72,7 @@ def read_config_file(path):
     return out
 
 
-def config_from_dict(d, output_rate=None, section_delay=1):
+def config_from_dict(d, output_rate=None, section_delay=1, layout=0):
     c = OracleConfig()
     c.output_rate = float(d["output_rate"]) if output_rate is None else float(output_rate)
     c.waveform = int(float(d["waveform"]))
@@ -86,13 +87,14 @@ def config_from_dict(d, output_rate=None, section_delay=1):
     for i in range(8):
         c.radius_coef[i] = float(d["radius_%d_coef" % (i + 1)])
     c.section_delay = section_delay
+    c.layout = layout
     return c
 
 
-def male_config(output_rate=44100.0, section_delay=1, **overrides):
+def male_config(output_rate=44100.0, section_delay=1, layout=0, **overrides):
     d = read_config_file(VOICE_MALE)
     d.update({k: str(v) for k, v in overrides.items()})
-    return config_from_dict(d, output_rate, section_delay)
+    return config_from_dict(d, output_rate, section_delay, layout)
 
 
 _lib = None

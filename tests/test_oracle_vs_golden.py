@@ -19,13 +19,15 @@ KAT = {
     "ramp_m0": (88108, 3.076802642e+00, 1.228036941e-03),
     "const_m3": (88077, 1.073991490e+01, 1.668861834e-03),
     "ramp_m3": (88077, 4.196292139e+00, 2.267686650e-03),
+    "const_m4": (88077, 1.073981937e+01, 1.675571664e-03),
+    "ramp_m4": (88077, 4.196179109e+00, 2.232487779e-03),
 }
 
 
 def _oracle_config(case):
     base = oracle.read_config_file(oracle.VOICE_MALE)
     base.update({k: str(v) for k, v in case["overrides"].items()})
-    return oracle.config_from_dict(base, case["rate"], case["delay"])
+    return oracle.config_from_dict(base, case["rate"], case["delay"], case.get("layout", 0))
 
 
 @pytest.mark.parametrize("case", golden_cases.CASES, ids=lambda c: c["name"])
