@@ -10,6 +10,8 @@ N_PARAM = 16
 DEVICE_NONE = -1
 PRECISION_F64 = 0
 PRECISION_MIXED = 1
+TUBE_10_6 = 0
+TUBE_30_18 = 1
 TABLE_FIR, TABLE_SRC_H, TABLE_SRC_DH, TABLE_WAVETABLE = 0, 1, 2, 3
 _STATUS_UNSUPPORTED = 4
 
@@ -45,6 +47,8 @@ class Config(ctypes.Structure):
         ("radius_coef", ctypes.c_double * 8),
         ("section_delay", ctypes.c_int32),
         ("precision", ctypes.c_int32),
+        ("tube_layout", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
     ]
 
 
@@ -137,7 +141,7 @@ def read_config_file(path):
     return out
 
 
-def config_from_dict(d, output_rate=None, section_delay=1, precision=PRECISION_F64):
+def config_from_dict(d, output_rate=None, section_delay=1, precision=PRECISION_F64, tube_layout=TUBE_10_6):
     """Builds a gvtm_config from the merged vtm.txt + variant keys (VocalTractModel0.h:266-305)."""
     c = Config()
     c.output_rate = float(d["output_rate"]) if output_rate is None else float(output_rate)
@@ -154,6 +158,7 @@ def config_from_dict(d, output_rate=None, section_delay=1, precision=PRECISION_F
         c.radius_coef[i] = float(d["radius_%d_coef" % (i + 1)])
     c.section_delay = int(section_delay)
     c.precision = int(precision)
+    c.tube_layout = int(tube_layout)
     return c
 
 

@@ -19,7 +19,8 @@ namespace gvtm {
 std::map<std::string, std::string> read_key_value_file(const std::string& path);
 
 // vtm.txt keys (merged with the variant) -> gvtm_config.  `model` selects the semantics:
-// 0, 2 -> SectionDelay 1; 3 -> SectionDelay 3 (VocalTractModel.cpp:40-47); others are refused.
+// 0, 2 -> SectionDelay 1; 3 -> SectionDelay 3; 4 -> the 30+18-section tube (VocalTractModel.cpp:40-49);
+// others are refused.
 gvtm_config config_from_keys(const std::map<std::string, std::string>& keys, int precision);
 
 class BatchController {

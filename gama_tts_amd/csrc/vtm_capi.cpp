@@ -256,16 +256,16 @@ int gvtm_debug_set_phase_cycles(gvtm_plan* plan, unsigned long long* d_cycles)
 }
 
 /* Diagnostic hook: what each lane receives through the cross-lane primitives of the tube
- * wavefront (row_shr:1, row_shl:1, row_ror:6, row_ror:10); out[4][64] host ints. */
+ * wavefront (row_shr:1, row_shl:1, row_ror:6, row_ror:10, wave_shr:1, wave_shl:1); out[6][64] host ints. */
 int gvtm_debug_dpp_selftest(gvtm_plan* plan, int* out)
 {
 	if (!plan || !out || plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_INVALID_ARGUMENT, "needs a device plan");
 	hipError_t e = hipSetDevice(plan->device);
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	int* d = nullptr;
-	if ((e = hipMalloc(reinterpret_cast<void**>(&d), 256 * sizeof(int))) != hipSuccess) return fail_hip(e, "hipMalloc");
+	if ((e = hipMalloc(reinterpret_cast<void**>(&d), 384 * sizeof(int))) != hipSuccess) return fail_hip(e, "hipMalloc");
 	e = gvtm::launch_dpp_selftest(d, nullptr);
-	if (e == hipSuccess) e = hipMemcpy(out, d, 256 * sizeof(int), hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(out, d, 384 * sizeof(int), hipMemcpyDeviceToHost);
 	(void) hipFree(d);
 	if (e != hipSuccess) return fail_hip(e, "dpp selftest");
 	return GVTM_OK;

@@ -194,6 +194,8 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 		return err.str();
 	}
 	if (c.waveform != 0 && c.waveform != 1) return "waveform must be 0 (pulse) or 1 (sine)";
+	if (c.tube_layout != GVTM_TUBE_10_6 && c.tube_layout != GVTM_TUBE_30_18) return "unknown tube_layout";
+	if (c.tube_layout == GVTM_TUBE_30_18 && c.section_delay != 1) return "the 30+18-section tube (VocalTractModel4) runs with section_delay 1";
 	if (c.precision != GVTM_PRECISION_F64 && c.precision != GVTM_PRECISION_MIXED) return "unknown precision";
 	if (!(c.glottal_pulse_tp > 0.0) || c.glottal_pulse_tn_min < 0.0 || c.glottal_pulse_tn_max < c.glottal_pulse_tn_min ||
 			c.glottal_pulse_tp + c.glottal_pulse_tn_max > 100.0) {
@@ -206,6 +208,7 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 	DeviceConstants& k = out.k;
 	k = DeviceConstants{};
 	k.section_delay = c.section_delay;
+	k.layout = c.tube_layout;
 	k.waveform = c.waveform;
 	k.modulation = c.noise_modulation != 0;
 
@@ -223,7 +226,8 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 
 	// initializeSynthesizer (vtm/VocalTractModel0.h:338-392, VocalTractModel2.h:413-467)
 	const double speed = 331.4 + (0.6 * c.temperature);
-	k.sample_rate = static_cast<int>((speed * (10 * c.section_delay) * 100.0) / length);
+	const int sections = c.tube_layout == GVTM_TUBE_30_18 ? 30 : 10; // TOTAL_SECTIONS (VocalTractModel4.h:194 / VocalTractModel0.h:128)
+	k.sample_rate = static_cast<int>((speed * (sections * c.section_delay) * 100.0) / length);
 	if (k.sample_rate < 2000) return "internal sample rate too low";
 	const double nyquist = static_cast<float>(k.sample_rate) / 2.0f; // float arithmetic, as in the reference
 	k.breathiness = c.breathiness / 100.0;

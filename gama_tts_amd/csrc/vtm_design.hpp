@@ -29,6 +29,7 @@ struct DeviceConstants {
 	unsigned control_steps;   // steps per frame
 	float interp_coef;        // 1.0f / control_steps (float32, Controller.cpp:287)
 	int section_delay;
+	int layout;               // gvtm_tube_layout
 	// sources
 	int waveform;             // 0 pulse, 1 sine
 	int modulation;

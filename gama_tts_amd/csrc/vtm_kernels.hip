@@ -84,11 +84,11 @@ struct V2Shape {
 	static constexpr int XR = 512;
 };
 
-template <typename ST, int D, int U>
+template <typename ST, int D, int U, int LAYOUT = 0>
 static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
 	using S = V2Shape<sizeof(ST) == 4, U>;
-	auto fn = v2::vtm_synth_kernel<ST, D, S::U, S::C, S::NH, S::XR>;
+	auto fn = v2::vtm_synth_kernel<ST, D, S::U, S::C, S::NH, S::XR, LAYOUT>;
 	const size_t lds = v2::smem_bytes<ST, S::U, S::C, S::XR>();
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
@@ -111,6 +111,7 @@ int synth_rows(bool mixed, size_t batch, int requested)
 	// instruction streams once there are more utterances than compute units.
 	const int max_rows = mixed ? 4 : 2; // fp64 resampler tables leave LDS for two rows only
 	int rows = requested;
+	(void) batch;
 	if (rows != 1 && rows != 2 && rows != 4) {
 		rows = batch > 512 ? 4 : (batch > 256 ? 2 : 1);
 	}
@@ -134,6 +135,11 @@ size_t synth_lds_bytes(bool mixed, int generation, int rows)
 template <typename ST, int U>
 static hipError_t launch_v2_d(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
+	if (args.k.layout == 1) {
+		// VocalTractModel4: 48 section lanes = one utterance per tube wavefront, SectionDelay 1 only
+		if (args.k.section_delay != 1) return hipErrorInvalidValue;
+		return launch_v2<ST, 1, 1, 1>(args, batch, stream);
+	}
 	switch (args.k.section_delay) {
 	case 1: return launch_v2<ST, 1, U>(args, batch, stream);
 	case 2: return launch_v2<ST, 2, U>(args, batch, stream);

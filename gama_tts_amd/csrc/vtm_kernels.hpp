@@ -49,7 +49,7 @@ struct NormalizeArgs {
 int synth_rows(bool mixed, size_t batch, int requested);
 size_t synth_lds_bytes(bool mixed, int generation, int rows);
 hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, int rows, hipStream_t stream);
-hipError_t launch_dpp_selftest(int* d_out /* [256] */, hipStream_t stream);
+hipError_t launch_dpp_selftest(int* d_out /* [384] */, hipStream_t stream);
 hipError_t launch_normalize(const NormalizeArgs& args, size_t batch, hipStream_t stream);
 
 } // namespace gvtm

@@ -92,6 +92,7 @@ public:
 		for (int i = 0; i < 5; ++i) c.nasal_radius[i] = k.number(nasal_keys[i]);
 		for (int i = 0; i < 8; ++i) c.radius_coef[i] = k.number(coef_keys[i]);
 		c.section_delay = k.has("section_delay") ? k.integer("section_delay") : 1;
+		c.tube_layout = k.has("tube_layout") ? k.integer("tube_layout") : GVTM_TUBE_10_6;
 		c.precision = k.text("gpu_precision", "f64") == "mixed" ? GVTM_PRECISION_MIXED : GVTM_PRECISION_F64;
 		const int device = k.has("gpu_device") ? k.integer("gpu_device") : 0;
 

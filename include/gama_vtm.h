@@ -9,9 +9,10 @@
  *
  * Reference interfaces each entry replaces (paths under gama_tts/src/):
  *
- *   gvtm_plan_create            VocalTractModel0/2 constructor: loadConfiguration +
+ *   gvtm_plan_create            VocalTractModel0/2/4 constructor: loadConfiguration +
  *                               initializeSynthesizer (vtm/VocalTractModel0.h:255-305, :338-392;
- *                               vtm/VocalTractModel2.h:322-376, :413-467) for a whole batch
+ *                               vtm/VocalTractModel2.h:322-376, :413-467; vtm/VocalTractModel4.h:370-515)
+ *                               for a whole batch
  *   gvtm_plan_info              VocalTractModel::internalSampleRate/outputSampleRate
  *                               (vtm/VocalTractModel.h:51-52) and the controlSteps of
  *                               Controller::synthesize (vtm_control_model/Controller.cpp:286)
@@ -58,6 +59,13 @@ typedef enum gvtm_precision {
 	GVTM_PRECISION_MIXED = 1 /* fp64 sources, tube and filters; fp32 sample-rate converter (tables, window, MACs) */
 } gvtm_precision;
 
+/* Tube topology. */
+typedef enum gvtm_tube_layout {
+	GVTM_TUBE_10_6 = 0,  /* 10 oropharynx + 6 nasal sections: VocalTractModel0 / VocalTractModel2 (models 0, 2, 3) */
+	GVTM_TUBE_30_18 = 1  /* 30 + 18 sections, scattering at region boundaries only: VocalTractModel4 (model 4,
+	                        vtm/VocalTractModel4.h); SectionDelay 1 */
+} gvtm_tube_layout;
+
 /* The configuration keys VocalTractModel0/2::loadConfiguration reads from the merged
  * vtm.txt + variant file (vtm/VocalTractModel0.h:266-305), as numbers. */
 typedef struct gvtm_config {
@@ -84,6 +92,8 @@ typedef struct gvtm_config {
 	double radius_coef[8];  /* radius_1_coef .. radius_8_coef */
 	int32_t section_delay;  /* VocalTractModel2's SectionDelay; 1 == VocalTractModel0 (models 0/2), 3 == model 3 */
 	int32_t precision;      /* gvtm_precision */
+	int32_t tube_layout;    /* gvtm_tube_layout */
+	int32_t reserved_;      /* must be 0 */
 } gvtm_config;
 
 typedef struct gvtm_info {

@@ -29,7 +29,7 @@
  *     writes the reason to stderr.
  *   - Optional extra keys in vtm.txt: `gpu_device` (int, default 0), `gpu_precision`
  *     ("f64" default | "mixed"), `section_delay` (1..4, default 1: VocalTractModel0 semantics;
- *     3 reproduces model 3).
+ *     3 reproduces model 3), `tube_layout` (0 default; 1 = the 30+18-section tube of model 4).
  */
 #ifndef GAMA_VTM_PLUGIN_H_
 #define GAMA_VTM_PLUGIN_H_

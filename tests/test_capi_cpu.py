@@ -28,11 +28,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
-@pytest.mark.parametrize("delay,rate", [(1, 44100.0), (1, 48000.0), (2, 44100.0), (3, 44100.0), (1, 16000.0)])
-def test_design_matches_oracle_bit_for_bit(delay, rate):
+@pytest.mark.parametrize("delay,rate,layout", [(1, 44100.0, 0), (1, 48000.0, 0), (2, 44100.0, 0), (3, 44100.0, 0), (1, 16000.0, 0),
+                                               (1, 44100.0, 1), (1, 22050.0, 1)])
+def test_design_matches_oracle_bit_for_bit(delay, rate, layout):
     d = g.read_config_file(oracle.VOICE_MALE)
-    plan = g.Plan(g.config_from_dict(d, rate, delay), 250.0, capi.DEVICE_NONE)
-    ocfg = oracle.male_config(rate, delay)
+    plan = g.Plan(g.config_from_dict(d, rate, delay, tube_layout=layout), 250.0, capi.DEVICE_NONE)
+    ocfg = oracle.male_config(rate, delay, layout)
     od = oracle.derive(ocfg)
     i = plan.info
     assert (i.internal_sample_rate, i.control_steps, i.fir_taps) == (od.sample_rate, od.control_steps, od.fir_taps)

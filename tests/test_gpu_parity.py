@@ -21,10 +21,10 @@ TOL_F64 = 1e-9
 TOL_MIXED = 1e-5
 
 
-def _plan(case_overrides=None, rate=44100.0, delay=1, crate=250.0, precision=capi.PRECISION_F64):
+def _plan(case_overrides=None, rate=44100.0, delay=1, crate=250.0, precision=capi.PRECISION_F64, layout=0):
     d = g.read_config_file(oracle.VOICE_MALE)
     d.update({k: str(v) for k, v in (case_overrides or {}).items()})
-    return g.Plan(g.config_from_dict(d, rate, delay, precision), crate, 0)
+    return g.Plan(g.config_from_dict(d, rate, delay, precision, layout), crate, 0)
 
 
 def _peak_err(got, ref):
@@ -41,7 +41,7 @@ def _peak_err(got, ref):
 def test_reference_vectors(case, precision, tol, golden):
     m = golden["manifest"][case["name"]]
     tr = golden_cases.track_for(case, golden)
-    plan = _plan(case["overrides"], case["rate"], case["delay"], case["crate"], precision)
+    plan = _plan(case["overrides"], case["rate"], case["delay"], case["crate"], precision, case.get("layout", 0))
     assert plan.info.internal_sample_rate == int(m["fs"])
     assert plan.output_count(tr.shape[0]) == m["n"]
     audio, counts, maxabs = plan.synthesize_host(tr[None])
@@ -196,3 +196,18 @@ def test_long_form_oversampled_tube(precision, tol):
         assert ref.size == n
         assert _peak_err(audio[b], ref) <= tol
         assert np.array_equal(audio[b], audio[b + 2]) and np.array_equal(audio[b], audio[b + 4])
+
+
+def test_thirty_section_tube_batch_against_oracle():
+    """VocalTractModel4 semantics (30 + 18 sections, one utterance per 48-lane tube wavefront),
+    ragged batch, against the oracle."""
+    frames = np.array([30, 0, 7, 30, 19], dtype=np.int32)
+    params = tracks.random_tracks(len(frames), 30, seed0=440, consonant_heavy=True)
+    plan = _plan(layout=1)
+    assert plan.info.internal_sample_rate == 60102
+    audio, counts, _ = plan.synthesize_host(params, frames)
+    cfg = oracle.male_config(44100.0, 1, 1)
+    for b, f in enumerate(frames):
+        ref = oracle.synthesize(cfg, params[b, :f]) if f else np.zeros(oracle.output_count(cfg, 0), np.float32)
+        assert counts[b] == ref.size
+        assert _peak_err(audio[b, : ref.size], ref) <= TOL_F64

@@ -15,9 +15,10 @@ import tracks  # noqa: E402
 delay = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 prec = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+layout = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 params = tracks.random_tracks(2, frames, seed0=42, consonant_heavy=True)
 cfgd = g.read_config_file(oracle.VOICE_MALE)
-plan = g.Plan(g.config_from_dict(cfgd, 44100.0, delay, prec), 250.0, 0)
+plan = g.Plan(g.config_from_dict(cfgd, 44100.0, delay, prec, layout), 250.0, 0)
 steps = frames * plan.info.control_steps
 n = plan.output_count(frames)
 dev = torch.device("cuda:0")
@@ -33,7 +34,7 @@ taps = d_taps.cpu().numpy()
 audio = d_audio.cpu().numpy()
 names = ["u", "sig", "thr", "fir", "lpnoise", "pos0", "pos1", "x"]
 for b in range(2):
-    ref_audio, ref_taps = oracle.synthesize_debug(oracle.male_config(44100.0, delay), params[b])
+    ref_audio, ref_taps = oracle.synthesize_debug(oracle.male_config(44100.0, delay, layout), params[b])
     for i, nm in enumerate(names):
         d = np.abs(taps[b, :, i] - ref_taps[:, i])
         first = int(np.argmax(d > 1e-9 * max(1e-30, np.abs(ref_taps[:, i]).max()))) if d.max() > 0 else -1
