@@ -34,8 +34,26 @@ def test_plugin_through_reference_loader(name, golden, tmp_path):
     assert err <= 1e-9, err
 
 
-def _make_voice_dir(root):
+def test_plugin_thirty_section_tube_through_reference_loader(golden, tmp_path):
+    """`tube_layout = 1` in vtm.txt makes the plugin stand in for model 4 (VocalTractModel4)."""
     keys = oracle.read_config_file(oracle.VOICE_MALE)
+    keys["tube_layout"] = "1"
+    cfg = str(tmp_path / "vtm4.txt")
+    with open(cfg, "w") as f:
+        for k, v in keys.items():
+            f.write("%s = %s\n" % (k, v))
+    import golden_cases
+    case = next(c for c in golden_cases.CASES if c["name"] == "rand5_m4")
+    tr = golden_cases.track_for(case, golden)
+    out, info = oracle.ref_synthesize(tr, "2000:" + PLUGIN, config=cfg, tmpdir=str(tmp_path))
+    ref = golden["rand5_m4__out"]
+    assert out.size == ref.size and float(info["fs"]) == 60102.0
+    assert np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max() <= 1e-9
+
+
+def _make_voice_dir(root, model="0"):
+    keys = oracle.read_config_file(oracle.VOICE_MALE)
+    keys["model"] = model
     os.makedirs(os.path.join(root, "variant"))
     variant_keys = ("vocal_tract_length", "glottal_pulse_tp", "glottal_pulse_tn_min", "glottal_pulse_tn_max",
                     "reference_glottal_pitch", "breathiness", "aperture_radius", "intonation_factor")
@@ -62,11 +80,12 @@ def _read_wav(path):
     return fmt, np.frombuffer(data[44:44 + n], dtype="<i2")
 
 
-def test_batched_vtm_cli_writes_reference_wavs(golden, tmp_path):
+@pytest.mark.parametrize("model,layout", [("0", 0), ("4", 1)])
+def test_batched_vtm_cli_writes_reference_wavs(model, layout, golden, tmp_path):
     """`gama_vtm_batch voice_dir out_dir a.txt b.txt` == `gama_tts vtm` per file: same frames in,
     same 16-bit samples out (scale 0.95/max, round(x * 32767), WAVEFileWriter.cpp:62-125)."""
     voice = str(tmp_path / "voice")
-    _make_voice_dir(voice)
+    _make_voice_dir(voice, model)
     out_dir = str(tmp_path / "out")
     os.makedirs(out_dir)
     tracks_ = {"hello": np.asarray(golden["hello_params"]), "short": np.asarray(golden["hello_params"])[:40]}
@@ -79,7 +98,7 @@ def test_batched_vtm_cli_writes_reference_wavs(golden, tmp_path):
         files.append(p)
     r = subprocess.run([CLI, voice, out_dir] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    cfg = oracle.male_config()
+    cfg = oracle.male_config(layout=layout)
     for name, tr in tracks_.items():
         fmt, pcm = _read_wav(os.path.join(out_dir, name + ".wav"))
         assert fmt == (16, 1, 1, 44100, 88200, 2, 16)
