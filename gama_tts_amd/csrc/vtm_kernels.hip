@@ -76,10 +76,13 @@ static hipError_t launch_v1(const SynthArgs& args, size_t batch, size_t lds, hip
 
 // generation-2 geometry: utterances per workgroup (DPP rows), chunk length, helper wavefronts,
 // internal-rate ring length
-template <bool MIXED, int U_>
+template <bool MIXED, int U_, int D_ = 1>
 struct V2Shape {
 	static constexpr int U = U_;
-	static constexpr int C = (U_ == 1) ? 48 : 24; // 12 divides by every SectionDelay; LDS caps U * C
+	// chunk length: a multiple of 4 (scan blocks) and of the tube unroll (2 for SectionDelay 1, D for
+	// even D, 6 for 3), i.e. of 12; at most 64 so that a stage is one pass when U = 1 (60 also avoids
+	// the power-of-two LDS strides of 64, measured 4% slower); LDS caps U * C
+	static constexpr int C = (U_ == 1) ? 60 : 24;
 	static constexpr int NH = (U_ == 1) ? 3 : 7; // 8 resp. 12 wavefronts per workgroup
 	static constexpr int XR = 512;
 };
@@ -87,7 +90,7 @@ struct V2Shape {
 template <typename ST, int D, int U, int LAYOUT = 0>
 static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
-	using S = V2Shape<sizeof(ST) == 4, U>;
+	using S = V2Shape<sizeof(ST) == 4, U, D>;
 	auto fn = v2::vtm_synth_kernel<ST, D, S::U, S::C, S::NH, S::XR, LAYOUT>;
 	const size_t lds = v2::smem_bytes<ST, S::U, S::C, S::XR>();
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
