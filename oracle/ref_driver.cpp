@@ -18,6 +18,7 @@
 //   <model>: 0,1,2,3,4,5,2000 = VocalTractModel::getInstance factory
 //            (gama_tts/src/vtm/VocalTractModel.cpp:35-59);
 //            "2:D" = VocalTractModel2<double,D> instantiated directly, D in 1..4
+//            "2f:D" = VocalTractModel2<float,D> (no factory number), "4f" = VocalTractModel4<float,1>
 //            "2000:<path>" = plugin factory with dll_path=<path>
 //   [repeat] > 1: timing mode, the utterance is synthesised <repeat> times
 //            (reset() between runs, as Controller does, Controller.cpp:231).
@@ -35,6 +36,7 @@
 #include "ConfigurationData.h"
 #include "VocalTractModel.h"
 #include "VocalTractModel2.h"
+#include "VocalTractModel4.h"
 
 using GS::ConfigurationData;
 using GS::VTM::VocalTractModel;
@@ -54,6 +56,25 @@ static std::unique_ptr<VocalTractModel> make_model(ConfigurationData& cfg, const
 			std::fprintf(stderr, "unsupported SectionDelay %d\n", d);
 			std::exit(2);
 		}
+	}
+	if (model.rfind("2f:", 0) == 0) {
+		const int d = std::atoi(model.c_str() + 3);
+		cfg.put("model", "2");
+		cfg.put("log_parameters", "false");
+		switch (d) {
+		case 1: return std::make_unique<GS::VTM::VocalTractModel2<float, 1>>(cfg, false);
+		case 2: return std::make_unique<GS::VTM::VocalTractModel2<float, 2>>(cfg, false);
+		case 3: return std::make_unique<GS::VTM::VocalTractModel2<float, 3>>(cfg, false);
+		case 4: return std::make_unique<GS::VTM::VocalTractModel2<float, 4>>(cfg, false);
+		default:
+			std::fprintf(stderr, "unsupported SectionDelay %d\n", d);
+			std::exit(2);
+		}
+	}
+	if (model == "4f") {
+		cfg.put("model", "4");
+		cfg.put("log_parameters", "false");
+		return std::make_unique<GS::VTM::VocalTractModel4<float, 1>>(cfg, false);
 	}
 	if (model.rfind("2000:", 0) == 0) {
 		cfg.put("model", "2000");

@@ -1,8 +1,8 @@
 /*
  * TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT.
  *
- * CPU restatement (plain C, scalar, fp64) of GamaTTS's vocal-tract-model hot
- * path, used only as the parity checker by tests/, __graft_entry__.smoke() and
+ * CPU restatement (plain C, scalar; TFloat = double and TFloat = float) of GamaTTS's
+ * vocal-tract-model hot path, used only as the parity checker by tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg.  Nothing under gama_tts_amd/ may include, link
  * or call it.
  *
@@ -14,7 +14,7 @@
  *
  * What it restates (reference file:line in vtm_oracle.c next to each function):
  *   Controller::synthesize                      vtm_control_model/Controller.cpp:277-313
- *   VocalTractModel0<double> / VocalTractModel2<double,D> / VocalTractModel4<double,D>
+ *   VocalTractModel0<TFloat> / VocalTractModel2<TFloat,D> / VocalTractModel4<TFloat,1>, TFloat = double | float
  *                                               vtm/VocalTractModel0.h, vtm/VocalTractModel2.h, vtm/VocalTractModel4.h
  *   WavetableGlottalSource (+FIR), SampleRateConverter, BandpassFilter,
  *   NoiseSource/NoiseFilter, Radiation/ReflectionFilter, Throat, VTMUtil
@@ -59,6 +59,8 @@ typedef struct vtmo_config {
 	double radius_coef[8];            /* radius_1_coef..radius_8_coef */
 	int    section_delay;             /* VocalTractModel2's SectionDelay template argument; 1 == VocalTractModel0 */
 	int    layout;                    /* 0: 10 + 6 sections (VocalTractModel0/2); 1: 30 + 18 sections (VocalTractModel4) */
+	int    float_model;               /* 0: TFloat = double (models 0, 2, 3, 4); 1: TFloat = float (model 1 = VocalTractModel0<float>,
+	                                     VocalTractModel2<float,D>, VocalTractModel4<float,1>) */
 } vtmo_config;
 
 /* Design-time quantities derived from the configuration. */
@@ -81,6 +83,13 @@ int vtmo_derive(const vtmo_config* cfg, double control_rate, vtmo_derived* out);
 int  vtmo_fir_coefficients(double* coef /* [VTMO_FIR_MAX_TAPS] */);
 void vtmo_src_filter(double* h /* [3328] */, double* delta_h /* [3328] */);
 void vtmo_wavetable(const vtmo_config* cfg, int sample_rate, double* table /* [512] */);
+/* the same tables as the TFloat = float models design them (float arithmetic throughout; 47 FIR taps) */
+int  vtmo_fir_coefficients_f32(float* coef /* [VTMO_FIR_MAX_TAPS] */);
+void vtmo_src_filter_f32(float* h /* [3328] */, float* delta_h /* [3328] */);
+void vtmo_wavetable_f32(const vtmo_config* cfg, int sample_rate, float* table /* [512] */);
+int  vtmo_fir_coefficients_f64(double* coef);
+void vtmo_src_filter_f64(double* h, double* delta_h);
+void vtmo_wavetable_f64(const vtmo_config* cfg, int sample_rate, double* table);
 /* lpNoise[n] of VocalTractModel0.h:408 for n = 0..count-1 (same for every utterance). */
 void vtmo_noise_sequence(double* lp_noise, size_t count);
 

@@ -33,9 +33,10 @@ def track_for(case, golden=None):
     return _track(case["track"], golden)
 
 
-def C(name, track, model="0", delay=1, rate=44100.0, crate=250.0, store="full", layout=0, **ov):
+def C(name, track, model="0", delay=1, rate=44100.0, crate=250.0, store="full", layout=0, fm=0, **ov):
+    # fm = 1: the reference model computes in float (TFloat = float)
     return dict(name=name, track=track, model=model, delay=delay, rate=rate, crate=crate, store=store, layout=layout,
-                overrides=ov)
+                float_model=fm, overrides=ov)
 
 
 CASES = [
@@ -83,6 +84,30 @@ CASES = [
     C("rand5_m4_48k", ("random", 120, 5, True), model="4", layout=1, rate=48000.0),
     C("rand6_m4_22k_crate500", ("random", 120, 6, False), model="4", layout=1, rate=22050.0, crate=500.0),
     C("two_frames_m4", ("random", 120, 5, True, 2), model="4", layout=1),
+    # TFloat = float: model 1 = VocalTractModel0<float> from the factory; VocalTractModel2<float,D> and
+    # VocalTractModel4<float,1> instantiated directly by oracle/ref_driver.cpp ("2f:D", "4f")
+    C("const_m1", ("const", 500), model="1", fm=1, store="digest"),
+    C("ramp_m1", ("ramp", 500), model="1", fm=1, store="digest"),
+    C("rand1000_m1", ("random", 500, 1000, False), model="1", fm=1, store="digest"),
+    C("cons2000_m1", ("random", 500, 2000, True), model="1", fm=1, store="digest"),
+    C("hello_m1", ("hello",), model="1", fm=1, store="digest"),
+    C("rand5_m1", ("random", 120, 5, True), model="1", fm=1),
+    C("rand5_m2f_d2", ("random", 120, 5, True), model="2f:2", delay=2, fm=1),
+    C("rand5_m2f_d3", ("random", 120, 5, True), model="2f:3", delay=3, fm=1),
+    C("rand5_m4f", ("random", 120, 5, True), model="4f", layout=1, fm=1),
+    C("tn_delta_m1", ("random", 120, 5, True), model="1", fm=1, glottal_pulse_tn_min=16.0, glottal_pulse_tn_max=32.0),
+    C("sine_m1", ("random", 120, 5, True), model="1", fm=1, waveform=1),
+    C("no_modulation_m1", ("random", 120, 5, True), model="1", fm=1, noise_modulation=0),
+    C("out48k_m1", ("random", 120, 5, True), model="1", fm=1, rate=48000.0),
+    C("out16k_down_m1", ("random", 120, 5, True), model="1", fm=1, rate=16000.0),
+    C("crate1000_m1", ("random", 120, 5, True), model="1", fm=1, crate=1000.0),
+    C("female_m1", ("random", 120, 6, False), model="1", fm=1, vocal_tract_length=15.0, glottal_pulse_tn_min=32.0,
+      glottal_pulse_tn_max=32.0, breathiness=1.5),
+    C("radius_coefs_m1", ("random", 120, 8, True), model="1", fm=1, radius_3_coef=1.3, global_radius_coef=0.9,
+      global_nasal_radius_coef=1.1, vocal_tract_length_offset=1.0),
+    C("silence_m1", ("silence", 40), model="1", fm=1),
+    C("one_frame_m1", ("random", 120, 5, True, 1), model="1", fm=1),
+    C("three_frames_m2f_d2", ("random", 120, 5, True, 3), model="2f:2", delay=2, fm=1),
 ]
 
 DIGEST_STRIDE = 97

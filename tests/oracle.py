@@ -41,6 +41,7 @@ class OracleConfig(ctypes.Structure):
         ("radius_coef", ctypes.c_double * 8),
         ("section_delay", ctypes.c_int),
         ("layout", ctypes.c_int),
+        ("float_model", ctypes.c_int),
     ]
 
 
@@ -72,7 +73,7 @@ def read_config_file(path):
     return out
 
 
-def config_from_dict(d, output_rate=None, section_delay=1, layout=0):
+def config_from_dict(d, output_rate=None, section_delay=1, layout=0, float_model=0):
     c = OracleConfig()
     c.output_rate = float(d["output_rate"]) if output_rate is None else float(output_rate)
     c.waveform = int(float(d["waveform"]))
@@ -88,13 +89,14 @@ def config_from_dict(d, output_rate=None, section_delay=1, layout=0):
         c.radius_coef[i] = float(d["radius_%d_coef" % (i + 1)])
     c.section_delay = section_delay
     c.layout = layout
+    c.float_model = int(float_model)
     return c
 
 
-def male_config(output_rate=44100.0, section_delay=1, layout=0, **overrides):
+def male_config(output_rate=44100.0, section_delay=1, layout=0, float_model=0, **overrides):
     d = read_config_file(VOICE_MALE)
     d.update({k: str(v) for k, v in overrides.items()})
-    return config_from_dict(d, output_rate, section_delay, layout)
+    return config_from_dict(d, output_rate, section_delay, layout, float_model)
 
 
 _lib = None
@@ -107,8 +109,9 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        src = os.path.join(ORACLE_DIR, "vtm_oracle.c")
-        if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("vtm_oracle.c", "vtm_oracle_body.inc", "vtm_oracle_f64.c",
+                                                       "vtm_oracle_f32.c", "vtm_oracle.h")]
+        if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
             build()
         L = ctypes.CDLL(LIB_PATH)
         P = ctypes.POINTER
@@ -118,6 +121,10 @@ def lib():
         L.vtmo_fir_coefficients.restype = ctypes.c_int
         L.vtmo_src_filter.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.vtmo_wavetable.argtypes = [P(OracleConfig), ctypes.c_int, ctypes.c_void_p]
+        L.vtmo_fir_coefficients_f32.argtypes = [ctypes.c_void_p]
+        L.vtmo_fir_coefficients_f32.restype = ctypes.c_int
+        L.vtmo_src_filter_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.vtmo_wavetable_f32.argtypes = [P(OracleConfig), ctypes.c_int, ctypes.c_void_p]
         L.vtmo_noise_sequence.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         L.vtmo_output_count.argtypes = [P(OracleConfig), ctypes.c_double, ctypes.c_size_t]
         L.vtmo_output_count.restype = ctypes.c_size_t

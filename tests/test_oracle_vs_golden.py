@@ -27,7 +27,7 @@ KAT = {
 def _oracle_config(case):
     base = oracle.read_config_file(oracle.VOICE_MALE)
     base.update({k: str(v) for k, v in case["overrides"].items()})
-    return oracle.config_from_dict(base, case["rate"], case["delay"], case.get("layout", 0))
+    return oracle.config_from_dict(base, case["rate"], case["delay"], case.get("layout", 0), case.get("float_model", 0))
 
 
 @pytest.mark.parametrize("case", golden_cases.CASES, ids=lambda c: c["name"])
