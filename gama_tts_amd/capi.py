@@ -10,6 +10,7 @@ N_PARAM = 16
 DEVICE_NONE = -1
 PRECISION_F64 = 0
 PRECISION_MIXED = 1
+PRECISION_F32 = 2  # everything in float, like the reference's TFloat = float models (model 1)
 TUBE_10_6 = 0
 TUBE_30_18 = 1
 TABLE_FIR, TABLE_SRC_H, TABLE_SRC_DH, TABLE_WAVETABLE = 0, 1, 2, 3

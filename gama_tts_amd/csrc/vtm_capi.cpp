@@ -60,13 +60,14 @@ struct EventPair {
 struct gvtm_plan {
 	gvtm::Design design;
 	int device = 0;
-	bool mixed = false;
+	int precision = GVTM_PRECISION_F64;
 	int generation = 2; // kernel generation; GVTM_KERNEL=1 selects the round-1 baseline for A/B runs
 	int rows = 0;       // utterances per workgroup; 0 = by batch size, GVTM_ROWS=1|2|4 forces it (tests)
-	double* d_wavetable = nullptr;
-	double* d_fir = nullptr;
-	double* d_src_h = nullptr;
-	double* d_src_dh = nullptr;
+	// design tables on the device: double, or float (as designed) for GVTM_PRECISION_F32
+	void* d_wavetable = nullptr;
+	void* d_fir = nullptr;
+	void* d_src_h = nullptr;
+	void* d_src_dh = nullptr;
 	gvtm::DeviceConstants* d_consts = nullptr;
 	// staging for the host-buffer entry point
 	DeviceBuffer s_params, s_frames, s_audio, s_counts, s_maxabs;
@@ -80,8 +81,8 @@ struct gvtm_plan {
 
 namespace {
 
-template <typename T>
-hipError_t upload(T** dst, const std::vector<T>& src)
+template <typename P, typename T>
+hipError_t upload(P** dst, const std::vector<T>& src)
 {
 	hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), sizeof(T) * src.size());
 	if (e != hipSuccess) return e;
@@ -148,7 +149,7 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 		std::unique_ptr<gvtm_plan, void (*)(gvtm_plan*)> plan(new gvtm_plan, free_plan);
 		const std::string why = gvtm::design_plan(*config, control_rate, plan->design);
 		if (!why.empty()) return fail(GVTM_ERR_INVALID_ARGUMENT, why);
-		plan->mixed = config->precision == GVTM_PRECISION_MIXED;
+		plan->precision = config->precision;
 		if (const char* gen = std::getenv("GVTM_KERNEL")) plan->generation = (gen[0] == '1') ? 1 : 2;
 		if (const char* rows = std::getenv("GVTM_ROWS")) plan->rows = std::atoi(rows);
 
@@ -171,10 +172,18 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 		if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
 			return fail(GVTM_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
 		}
-		if ((e = upload(&plan->d_wavetable, plan->design.wavetable)) != hipSuccess) return fail_hip(e, "upload wavetable");
-		if ((e = upload(&plan->d_fir, plan->design.fir)) != hipSuccess) return fail_hip(e, "upload fir");
-		if ((e = upload(&plan->d_src_h, plan->design.src_h)) != hipSuccess) return fail_hip(e, "upload src_h");
-		if ((e = upload(&plan->d_src_dh, plan->design.src_dh)) != hipSuccess) return fail_hip(e, "upload src_dh");
+		const gvtm::Design& dg = plan->design;
+		if (dg.f32) {
+			if ((e = upload(&plan->d_wavetable, dg.wavetable_f)) != hipSuccess) return fail_hip(e, "upload wavetable");
+			if ((e = upload(&plan->d_fir, dg.fir_f)) != hipSuccess) return fail_hip(e, "upload fir");
+			if ((e = upload(&plan->d_src_h, dg.src_h_f)) != hipSuccess) return fail_hip(e, "upload src_h");
+			if ((e = upload(&plan->d_src_dh, dg.src_dh_f)) != hipSuccess) return fail_hip(e, "upload src_dh");
+		} else {
+			if ((e = upload(&plan->d_wavetable, dg.wavetable)) != hipSuccess) return fail_hip(e, "upload wavetable");
+			if ((e = upload(&plan->d_fir, dg.fir)) != hipSuccess) return fail_hip(e, "upload fir");
+			if ((e = upload(&plan->d_src_h, dg.src_h)) != hipSuccess) return fail_hip(e, "upload src_h");
+			if ((e = upload(&plan->d_src_dh, dg.src_dh)) != hipSuccess) return fail_hip(e, "upload src_dh");
+		}
 		if ((e = upload(&plan->d_consts, std::vector<gvtm::DeviceConstants>(1, plan->design.k))) != hipSuccess) return fail_hip(e, "upload constants");
 		*plan_out = plan.release();
 		return GVTM_OK;
@@ -204,7 +213,7 @@ int gvtm_plan_info(const gvtm_plan* plan, gvtm_info* info)
 	info->pad_size = k.pad;
 	info->upsampling = k.upsampling;
 	info->device = plan->device;
-	info->precision = plan->mixed ? GVTM_PRECISION_MIXED : GVTM_PRECISION_F64;
+	info->precision = plan->precision;
 	info->section_delay = k.section_delay;
 	return GVTM_OK;
 }
@@ -263,16 +272,17 @@ int gvtm_debug_dpp_selftest(gvtm_plan* plan, int* out)
 	hipError_t e = hipSetDevice(plan->device);
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	int* d = nullptr;
-	if ((e = hipMalloc(reinterpret_cast<void**>(&d), 384 * sizeof(int))) != hipSuccess) return fail_hip(e, "hipMalloc");
+	if ((e = hipMalloc(reinterpret_cast<void**>(&d), gvtm::kDppSelftestInts * sizeof(int))) != hipSuccess) return fail_hip(e, "hipMalloc");
 	e = gvtm::launch_dpp_selftest(d, nullptr);
-	if (e == hipSuccess) e = hipMemcpy(out, d, 384 * sizeof(int), hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(out, d, gvtm::kDppSelftestInts * sizeof(int), hipMemcpyDeviceToHost);
 	(void) hipFree(d);
 	if (e != hipSuccess) return fail_hip(e, "dpp selftest");
 	return GVTM_OK;
 }
 
 /* Test hook: the short elementary functions of csrc/vtm_math.hpp evaluated on the host
- * (kind 0 = 2^x, 1 = 10^x, 2 = cos, 3 = tan). */
+ * (kind 0 = 2^x, 1 = 10^x, 2 = cos, 3 = tan; 4 = powf(2, x), 5 = powf(10, x), 6 = cosf, 7 = tanf of the
+ * all-float path, arguments and results carried as doubles). */
 int gvtm_debug_short_math(int kind, const double* x, size_t n, double* out)
 {
 	if (!x || !out) return GVTM_ERR_INVALID_ARGUMENT;
@@ -282,9 +292,33 @@ int gvtm_debug_short_math(int kind, const double* x, size_t n, double* out)
 		case 1: out[i] = gvtm::vmath::exp10_short(x[i]); break;
 		case 2: out[i] = gvtm::vmath::cos_short(x[i]); break;
 		case 3: out[i] = gvtm::vmath::tan_short(x[i]); break;
+		case 4: out[i] = gvtm::vmath::powf_base2(static_cast<float>(x[i])); break;
+		case 5: out[i] = gvtm::vmath::powf_base10(static_cast<float>(x[i])); break;
+		case 6: out[i] = gvtm::vmath::cosf_glibc(static_cast<float>(x[i])); break;
+		case 7: out[i] = gvtm::vmath::tanf_glibc(static_cast<float>(x[i])); break;
 		default: return GVTM_ERR_INVALID_ARGUMENT;
 		}
 	}
+	return GVTM_OK;
+}
+
+/* Test hook: Util::frequency / Util::amplitude60dB / tan / cos of the all-float path evaluated by a
+ * kernel on the plan's device (kind 0..3), host arrays in and out. */
+int gvtm_debug_device_float_math(gvtm_plan* plan, int kind, const float* x, size_t n, float* out)
+{
+	if (!plan || !x || !out || kind < 0 || kind > 3) return fail(GVTM_ERR_INVALID_ARGUMENT, "bad argument");
+	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan");
+	hipError_t e = hipSetDevice(plan->device);
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	float *dx = nullptr, *dout = nullptr;
+	if ((e = hipMalloc(reinterpret_cast<void**>(&dx), n * sizeof(float))) != hipSuccess) return fail_hip(e, "hipMalloc");
+	if ((e = hipMalloc(reinterpret_cast<void**>(&dout), n * sizeof(float))) != hipSuccess) { (void) hipFree(dx); return fail_hip(e, "hipMalloc"); }
+	e = hipMemcpy(dx, x, n * sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = gvtm::launch_float_math_probe(kind, dx, n, dout, nullptr);
+	if (e == hipSuccess) e = hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost);
+	(void) hipFree(dx);
+	(void) hipFree(dout);
+	if (e != hipSuccess) return fail_hip(e, "float math probe");
 	return GVTM_OK;
 }
 
@@ -333,8 +367,8 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	if (audio_stride < need) {
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
 	}
-	const int rows = gvtm::synth_rows(plan->mixed, batch, plan->rows);
-	if (gvtm::synth_lds_bytes(plan->mixed, plan->generation, rows) > 160 * 1024) return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
+	const int rows = gvtm::synth_rows(plan->precision, batch, plan->rows);
+	if (gvtm::synth_lds_bytes(plan->precision, plan->generation, rows) > 160 * 1024) return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
 
 	hipError_t e = hipSetDevice(plan->device);
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -369,7 +403,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 		}
 		if ((e = hipEventRecord(ev.start, stream)) != hipSuccess) return fail_hip(e, "hipEventRecord");
 	}
-	e = gvtm::launch_synth(args, batch, plan->mixed, plan->generation, rows, stream);
+	e = gvtm::launch_synth(args, batch, plan->precision, plan->generation, rows, stream);
 	if (plan->timing) {
 		(void) hipEventRecord(ev.stop, stream);
 		plan->pending.push_back(ev);

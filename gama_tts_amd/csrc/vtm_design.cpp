@@ -1,4 +1,4 @@
-// Design-time math for the batched vocal-tract model (host, fp64).
+// Design-time math for the batched vocal-tract model (host; fp64, or float for GVTM_PRECISION_F32).
 //
 // Each routine states which reference routine defines the numbers it must
 // reproduce; tests/test_design_tables.py compares every table with the oracle
@@ -15,33 +15,38 @@ namespace {
 
 constexpr double kPi = 3.14159265358979323846;
 
+// The reference's classes are templates over TFloat and write their literals as TFloat
+// (1.0f, TFloat{...}), so with TFloat = float every operation below is a float operation and
+// std::pow/cos/sin/sqrt/rint/abs resolve to the float overloads.  T plays TFloat here.
+
 // --- glottal-source anti-alias FIR -------------------------------------------------
 // Numbers defined by WavetableGlottalSourceFIRFilter::maximallyFlat / rationalApproximation /
 // trim (vtm/WavetableGlottalSourceFIRFilter.h:137-215, :316-361, :227-235) with
 // beta = 0.2, gamma = 0.1, cutoff = 1e-8 (vtm/WavetableGlottalSource.h:94-96).
 struct Rational { int numerator, denominator, order; };
 
-Rational best_rational(double value, int order)
+template <typename T>
+Rational best_rational(T value, int order)
 {
 	constexpr int kLimit = 200;
 	Rational r{0, 0, -1};
 	if (order <= 0) return r;
-	const double frac = std::fabs(value - static_cast<int>(value));
+	const T frac = std::abs(value - static_cast<int>(value));
 	const int max_den = std::min(2 * order, kLimit);
-	double best = 1.0;
+	T best = 1.0;
 	int best_num = 0;
 	for (int den = order; den <= max_den; ++den) {
-		const double scaled = den * frac;
-		const int nearest = static_cast<int>(scaled + 0.5);
-		const double err = std::fabs((scaled - static_cast<double>(nearest)) / den);
+		const T scaled = den * frac;
+		const int nearest = static_cast<int>(scaled + T(0.5));
+		const T err = std::abs((scaled - static_cast<double>(nearest)) / den); // evaluated in double (:339)
 		if (err < best) {
 			best = err;
 			best_num = nearest;
 			r.denominator = den;
 		}
 	}
-	r.numerator = static_cast<int>(std::fabs(value)) * r.denominator + best_num;
-	if (value < 0.0) r.numerator = -r.numerator;
+	r.numerator = static_cast<int>(std::abs(value)) * r.denominator + best_num;
+	if (value < T(0)) r.numerator = -r.numerator;
 	r.order = r.denominator - 1;
 	if (r.numerator == r.denominator) {
 		r.denominator = max_den;
@@ -50,50 +55,52 @@ Rational best_rational(double value, int order)
 	return r;
 }
 
-std::vector<double> design_glottal_fir()
+template <typename T>
+std::vector<T> design_glottal_fir()
 {
-	constexpr double beta = 0.2, gamma = 0.1, cutoff = 0.00000001;
+	const T beta = 0.2, gamma = 0.1, cutoff = 0.00000001;
 	constexpr int kLimit = 200;
-	const int nt0 = static_cast<int>(1.0 / (4.0 * gamma * gamma));
-	const double ac = (1.0 + std::cos((2.0 * kPi) * beta)) / 2.0;
-	const Rational q = best_rational(ac, nt0);
+	const int nt0 = static_cast<int>(T(1) / (T(4) * gamma * gamma));
+	const T ac = (T(1) + std::cos((T(2) * static_cast<T>(kPi)) * beta)) / T(2);
+	const Rational q = best_rational<T>(ac, nt0);
 	const int np = q.denominator;
 	const int nt = q.order;
 	const int numer = q.numerator == 0 ? 1 : q.numerator;
 	const int n = 2 * np - 1;
 
-	std::vector<double> mag(kLimit + 2, 0.0), cosv(kLimit + 2, 0.0), half(kLimit + 2, 0.0);
+	std::vector<T> mag(kLimit + 2, T(0)), cosv(kLimit + 2, T(0)), half(kLimit + 2, T(0));
 	mag[1] = cosv[1] = 1.0;
 	const int terms = nt - numer;
 	for (int i = 2; i <= np; ++i) {
-		cosv[i] = std::cos((2.0 * kPi) * (static_cast<double>(i - 1) / n));
-		const double x = (1.0 - cosv[i]) / 2.0;
+		cosv[i] = std::cos((T(2) * static_cast<T>(kPi)) * (static_cast<T>(i - 1) / n));
+		const T x = (T(1) - cosv[i]) / T(2);
 		if (numer == nt) continue;
-		double y = x, sum = 1.0;
+		T y = x, sum = 1.0;
 		for (int j = 1; j <= terms; ++j) {
-			double z = y;
-			for (int jj = 1; jj <= numer - 1; ++jj) z *= 1.0 + (static_cast<double>(j) / jj);
+			T z = y;
+			for (int jj = 1; jj <= numer - 1; ++jj) z *= T(1) + (static_cast<T>(j) / jj);
 			y *= x;
 			sum += z;
 		}
-		mag[i] = sum * std::pow(1.0 - x, numer);
+		// std::pow(TFloat, int) promotes to double, and so does the product
+		mag[i] = static_cast<T>(sum * std::pow(static_cast<double>(T(1) - x), static_cast<double>(numer)));
 	}
 	// N-point inverse DFT of the symmetric magnitude response
 	for (int i = 1; i <= np; ++i) {
-		double acc = mag[1] / 2.0;
+		T acc = mag[1] / T(2);
 		for (int j = 2; j <= np; ++j) {
 			int m = ((i - 1) * (j - 1)) % n;
 			if (m > nt) m = n - m;
 			acc += cosv[m + 1] * mag[j];
 		}
-		half[i] = acc * (2.0 / static_cast<double>(n));
+		half[i] = acc * (T(2) / static_cast<T>(n));
 	}
 	int keep = np;
 	for (int i = np; i > 0; --i) {
-		if (std::fabs(half[i]) >= std::fabs(cutoff)) { keep = i; break; }
+		if (std::abs(half[i]) >= std::abs(cutoff)) { keep = i; break; }
 	}
 	// mirror the half response into a linear-phase filter: h[keep] ... h[1] ... h[keep]
-	std::vector<double> taps;
+	std::vector<T> taps;
 	taps.reserve(2 * keep - 1);
 	for (int i = keep; i >= 1; --i) taps.push_back(half[i]);
 	for (int i = 2; i <= keep; ++i) taps.push_back(half[i]);
@@ -103,84 +110,193 @@ std::vector<double> design_glottal_fir()
 // --- sample-rate-converter prototype ------------------------------------------------
 // Kaiser-windowed sinc of SampleRateConverter::initializeFilter / Izero
 // (vtm/SampleRateConverter.h:230-255, :175-194).
-double bessel_i0(double x)
+template <typename T>
+T bessel_i0(T x)
 {
-	double sum = 1.0, term = 1.0;
-	const double half = x / 2.0;
+	T sum = 1, term = 1;
+	const T half = x / T(2);
+	const T eps = 1E-21;
 	int n = 1;
 	do {
-		double t = half / n;
+		T t = half / n;
 		n += 1;
 		t *= t;
 		term *= t;
 		sum += term;
-	} while (term >= 1E-21 * sum);
+	} while (term >= eps * sum);
 	return sum;
 }
 
-void design_src_filter(std::vector<double>& h, std::vector<double>& dh)
+template <typename T>
+void design_src_filter(std::vector<T>& h, std::vector<T>& dh)
 {
-	const double beta = 5.658;
-	const double cutoff = 11.0 / 13.0;
-	h.assign(kSrcFilterLength, 0.0);
-	dh.assign(kSrcFilterLength, 0.0);
+	const T beta = 5.658;
+	const T cutoff = 11.0 / 13.0;
+	h.assign(kSrcFilterLength, T(0));
+	dh.assign(kSrcFilterLength, T(0));
 	h[0] = cutoff;
-	const double dx = kPi / kSrcPhases;
+	const T dx = kPi / kSrcPhases;
 	for (unsigned i = 1; i < static_cast<unsigned>(kSrcFilterLength); ++i) {
-		const double y = i * dx;
+		const T y = i * dx;
 		h[i] = std::sin(y * cutoff) / y;
 	}
-	const double inv_i0 = 1.0 / bessel_i0(beta);
+	const T inv_i0 = T(1) / bessel_i0<T>(beta);
 	for (unsigned i = 0; i < static_cast<unsigned>(kSrcFilterLength); ++i) {
-		const double t = static_cast<double>(i) / kSrcFilterLength;
-		h[i] *= bessel_i0(beta * std::sqrt(1.0 - (t * t))) * inv_i0;
+		const T t = static_cast<T>(i) / kSrcFilterLength;
+		h[i] *= bessel_i0<T>(beta * std::sqrt(T(1) - (t * t))) * inv_i0;
 	}
 	for (int i = 0; i + 1 < kSrcFilterLength; ++i) dh[i] = h[i + 1] - h[i];
-	dh[kSrcFilterLength - 1] = 0.0 - h[kSrcFilterLength - 1];
+	dh[kSrcFilterLength - 1] = T(0) - h[kSrcFilterLength - 1];
 }
 
 // --- glottal wavetable ----------------------------------------------------------------
 // WavetableGlottalSource constructor (vtm/WavetableGlottalSource.h:90-141).
-void design_wavetable(const gvtm_config& c, DeviceConstants& k, std::vector<double>& table)
+template <typename T>
+void design_wavetable(const gvtm_config& c, DeviceConstants& k, std::vector<T>& table)
 {
 	const unsigned len = kWavetableLength;
-	k.table_div1 = static_cast<unsigned>(std::rint(len * (c.glottal_pulse_tp / 100.0)));
-	k.table_div2 = static_cast<unsigned>(std::rint(len * ((c.glottal_pulse_tp + c.glottal_pulse_tn_max) / 100.0)));
-	k.tn_delta = std::rint(len * ((c.glottal_pulse_tn_max - c.glottal_pulse_tn_min) / 100.0));
-	k.basic_increment = len / static_cast<double>(k.sample_rate);
-	table.assign(len, 0.0);
+	const T tp = static_cast<T>(c.glottal_pulse_tp), tn_min = static_cast<T>(c.glottal_pulse_tn_min),
+			tn_max = static_cast<T>(c.glottal_pulse_tn_max);
+	k.table_div1 = static_cast<unsigned>(std::rint(len * (tp / T(100))));
+	k.table_div2 = static_cast<unsigned>(std::rint(len * ((tp + tn_max) / T(100))));
+	k.tn_delta = std::rint(len * ((tn_max - tn_min) / T(100)));
+	k.basic_increment = len / static_cast<T>(k.sample_rate);
+	table.assign(len, T(0));
 	if (c.waveform == 0) {
-		const double fall = k.table_div2 - k.table_div1;
+		const T fall = k.table_div2 - k.table_div1;
 		for (unsigned i = 0; i < k.table_div1; ++i) {
-			const double x = static_cast<double>(i) / k.table_div1;
-			const double x2 = x * x;
-			table[i] = (3.0 * x2) - (2.0 * (x2 * x));
+			const T x = static_cast<T>(i) / k.table_div1;
+			const T x2 = x * x;
+			const T x3 = x2 * x;
+			table[i] = (T(3) * x2) - (T(2) * x3);
 		}
 		for (unsigned i = k.table_div1, j = 0; i < k.table_div2 && i < len; ++i, ++j) {
-			const double x = static_cast<double>(j) / fall;
-			table[i] = 1.0 - (x * x);
+			const T x = static_cast<T>(j) / fall;
+			table[i] = T(1) - (x * x);
 		}
 	} else {
 		for (unsigned i = 0; i < len; ++i) {
-			table[i] = std::sin((static_cast<double>(i) / len) * 2.0 * kPi);
+			table[i] = std::sin((static_cast<T>(i) / len) * T(2) * static_cast<T>(kPi));
 		}
 	}
 }
 
-double junction(double left_radius, double right_radius)
+template <typename T>
+T junction(T left_radius, T right_radius)
 {
-	const double a = left_radius * left_radius;
-	const double b = right_radius * right_radius;
+	const T a = left_radius * left_radius;
+	const T b = right_radius * right_radius;
 	return (a - b) / (a + b);
+}
+
+// Util::amplitude60dB (vtm/VTMUtil.h:48-67)
+template <typename T>
+T amplitude_60db_t(T db)
+{
+	if (db <= T(0)) return T(0);
+	if (db == T(60)) return T(1);
+	return std::pow(T(10), (db - T(60)) * static_cast<T>(1.0 / 20.0));
+}
+
+template <typename T>
+struct Tables {
+	std::vector<T> fir, src_h, src_dh, wavetable;
+};
+
+// Everything derived from the configuration, computed in T as the reference's TFloat does.
+template <typename T>
+std::string design_numbers(const gvtm_config& c, double control_rate, DeviceConstants& k, Tables<T>& tb)
+{
+	std::ostringstream err;
+	auto finite_pos = [](double v) { return std::isfinite(v) && v > 0.0; };
+
+	// loadConfiguration (vtm/VocalTractModel0.h:266-305): length clamp, radius scaling
+	T length = static_cast<T>(c.vocal_tract_length_offset) + static_cast<T>(c.vocal_tract_length);
+	length = std::min(std::max(length, T(3)), T(30));
+	const T global_radius = static_cast<T>(c.global_radius_coef);
+	const T global_nasal = static_cast<T>(c.global_nasal_radius_coef);
+	const T aperture = static_cast<T>(c.aperture_radius) * global_radius;
+	T nasal[6] = {T(0)};
+	for (int i = 0; i < 5; ++i) nasal[i + 1] = static_cast<T>(c.nasal_radius[i]) * global_nasal;
+	for (int i = 0; i < 8; ++i) k.radius_coef[i] = static_cast<T>(c.radius_coef[i]) * global_radius;
+	for (int i = 1; i < 6; ++i) {
+		if (!finite_pos(nasal[i])) return "nasal radii must be > 0";
+	}
+	if (!finite_pos(aperture)) return "aperture_radius must be > 0";
+
+	// initializeSynthesizer (vtm/VocalTractModel0.h:338-392, VocalTractModel2.h:413-467)
+	const T speed = T(331.4) + (T(0.6) * static_cast<T>(c.temperature));
+	const int sections = c.tube_layout == GVTM_TUBE_30_18 ? 30 : 10; // TOTAL_SECTIONS (VocalTractModel4.h:194 / VocalTractModel0.h:128)
+	k.sample_rate = static_cast<int>((speed * (sections * c.section_delay) * 100.0f) / length);
+	if (k.sample_rate < 2000) return "internal sample rate too low";
+	const T nyquist = k.sample_rate / 2.0f; // int / float -> float arithmetic, as in the reference
+	k.breathiness = static_cast<T>(c.breathiness) / T(100);
+	const T mix_amp = amplitude_60db_t<T>(static_cast<T>(c.mix_offset));
+	if (!(mix_amp > T(0))) return "mix_offset must be > 0 dB";
+	k.crossmix_factor = T(1) / mix_amp;
+	k.damping = T(1) - (static_cast<T>(c.loss_factor) / T(100));
+
+	const T mouth_ap = (nyquist - static_cast<T>(c.mouth_coefficient)) / nyquist;
+	k.mouth_b0_refl = T(1) - std::abs(mouth_ap); // ReflectionFilter.h:55-60
+	k.mouth_a1_refl = -mouth_ap;
+	k.mouth_a_rad = mouth_ap;                    // RadiationFilter.h:54-61: b0 = a, b1 = a1 = -a
+	const T nose_ap = (nyquist - static_cast<T>(c.nose_coefficient)) / nyquist;
+	k.nose_b0_refl = T(1) - std::abs(nose_ap);
+	k.nose_a1_refl = -nose_ap;
+	k.nose_a_rad = nose_ap;
+
+	// initializeNasalCavity (vtm/VocalTractModel0.h:457-470)
+	k.nasal_k[0] = 0.0;
+	for (int i = 1; i < 5; ++i) k.nasal_k[i] = junction<T>(nasal[i], nasal[i + 1]);
+	k.nasal_k[5] = junction<T>(nasal[5], aperture);
+	k.aperture_radius2 = aperture * aperture;
+	k.nasal_r2_sq = nasal[1] * nasal[1];
+
+	// Throat (vtm/Throat.h:52-60)
+	const T fs = static_cast<T>(k.sample_rate);
+	const T throat_b0 = (static_cast<T>(c.throat_cutoff) * T(2)) / fs;
+	k.throat_b0 = throat_b0;
+	k.throat_a1 = throat_b0 - T(1);
+	k.throat_gain = amplitude_60db_t<T>(static_cast<T>(c.throat_volume));
+	k.bp_T = T(1) / fs; // BandpassFilter::update (BandpassFilter.h:104)
+
+	// Controller::synthesize (vtm_control_model/Controller.cpp:286-287)
+	k.control_steps = static_cast<unsigned>(std::rint(static_cast<double>(k.sample_rate) / control_rate));
+	if (k.control_steps == 0) return "control_rate above the internal sample rate";
+	k.interp_coef = 1.0f / k.control_steps;
+
+	// SampleRateConverter::initializeConversion (vtm/SampleRateConverter.h:136-164)
+	const T ratio = static_cast<T>(c.output_rate) / fs;
+	k.src_ratio = ratio;
+	k.time_inc = static_cast<unsigned>(std::rint(std::pow(2.0, 16) / ratio)); // double arithmetic (:145)
+	if (k.time_inc == 0) return "output_rate too high for the 16.16 time register";
+	const T rounded_ratio = std::pow(2.0, 16) / k.time_inc;
+	k.upsampling = ratio >= T(1);
+	if (k.upsampling) {
+		k.phase_inc = 0;
+		k.pad = kSrcZeroCrossings;
+	} else {
+		k.phase_inc = static_cast<unsigned>(std::rint(ratio * 65536));
+		k.pad = static_cast<int>(kSrcZeroCrossings / rounded_ratio) + 1;
+	}
+	if (k.pad > kMaxPad || (k.phase_inc == 0 && !k.upsampling)) {
+		err << "output_rate / internal rate = " << static_cast<double>(ratio) << " is below the supported down-sampling range";
+		return err.str();
+	}
+
+	design_wavetable<T>(c, k, tb.wavetable);
+	tb.fir = design_glottal_fir<T>();
+	k.fir_taps = static_cast<int>(tb.fir.size());
+	if (k.fir_taps > kMaxFirTaps || k.fir_taps > 49) return "glottal FIR longer than the device pre-roll (49 taps)";
+	design_src_filter<T>(tb.src_h, tb.src_dh);
+	return "";
 }
 
 } // namespace
 
 double amplitude_60db(double db)
 {
-	if (db <= 0.0) return 0.0;
-	if (db == 60.0) return 1.0;
-	return std::pow(10.0, (db - 60.0) * (1.0 / 20.0));
+	return amplitude_60db_t<double>(db);
 }
 
 std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
@@ -196,7 +312,7 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 	if (c.waveform != 0 && c.waveform != 1) return "waveform must be 0 (pulse) or 1 (sine)";
 	if (c.tube_layout != GVTM_TUBE_10_6 && c.tube_layout != GVTM_TUBE_30_18) return "unknown tube_layout";
 	if (c.tube_layout == GVTM_TUBE_30_18 && c.section_delay != 1) return "the 30+18-section tube (VocalTractModel4) runs with section_delay 1";
-	if (c.precision != GVTM_PRECISION_F64 && c.precision != GVTM_PRECISION_MIXED) return "unknown precision";
+	if (c.precision != GVTM_PRECISION_F64 && c.precision != GVTM_PRECISION_MIXED && c.precision != GVTM_PRECISION_F32) return "unknown precision";
 	if (!(c.glottal_pulse_tp > 0.0) || c.glottal_pulse_tn_min < 0.0 || c.glottal_pulse_tn_max < c.glottal_pulse_tn_min ||
 			c.glottal_pulse_tp + c.glottal_pulse_tn_max > 100.0) {
 		return "glottal pulse shape needs tp > 0, 0 <= tn_min <= tn_max, tp + tn_max <= 100";
@@ -211,81 +327,24 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 	k.layout = c.tube_layout;
 	k.waveform = c.waveform;
 	k.modulation = c.noise_modulation != 0;
-
-	// loadConfiguration (vtm/VocalTractModel0.h:266-305): length clamp, radius scaling
-	double length = c.vocal_tract_length_offset + c.vocal_tract_length;
-	length = std::min(std::max(length, 3.0), 30.0);
-	const double aperture = c.aperture_radius * c.global_radius_coef;
-	double nasal[6] = {0.0};
-	for (int i = 0; i < 5; ++i) nasal[i + 1] = c.nasal_radius[i] * c.global_nasal_radius_coef;
-	for (int i = 0; i < 8; ++i) k.radius_coef[i] = c.radius_coef[i] * c.global_radius_coef;
-	for (int i = 1; i < 6; ++i) {
-		if (!finite_pos(nasal[i])) return "nasal radii must be > 0";
+	out.f32 = c.precision == GVTM_PRECISION_F32;
+	if (out.f32) {
+		// TFloat = float: every derived number and table is computed in float, as VocalTractModel0<float> does;
+		// the constants are carried in DeviceConstants' double fields (exact) and narrowed back on the device
+		Tables<float> tb;
+		const std::string msg = design_numbers<float>(c, control_rate, k, tb);
+		if (!msg.empty()) return msg;
+		out.fir_f = tb.fir; out.src_h_f = tb.src_h; out.src_dh_f = tb.src_dh; out.wavetable_f = tb.wavetable;
+		out.fir.assign(tb.fir.begin(), tb.fir.end());
+		out.src_h.assign(tb.src_h.begin(), tb.src_h.end());
+		out.src_dh.assign(tb.src_dh.begin(), tb.src_dh.end());
+		out.wavetable.assign(tb.wavetable.begin(), tb.wavetable.end());
+		return "";
 	}
-	if (!finite_pos(aperture)) return "aperture_radius must be > 0";
-
-	// initializeSynthesizer (vtm/VocalTractModel0.h:338-392, VocalTractModel2.h:413-467)
-	const double speed = 331.4 + (0.6 * c.temperature);
-	const int sections = c.tube_layout == GVTM_TUBE_30_18 ? 30 : 10; // TOTAL_SECTIONS (VocalTractModel4.h:194 / VocalTractModel0.h:128)
-	k.sample_rate = static_cast<int>((speed * (sections * c.section_delay) * 100.0) / length);
-	if (k.sample_rate < 2000) return "internal sample rate too low";
-	const double nyquist = static_cast<float>(k.sample_rate) / 2.0f; // float arithmetic, as in the reference
-	k.breathiness = c.breathiness / 100.0;
-	const double mix_amp = amplitude_60db(c.mix_offset);
-	if (!(mix_amp > 0.0)) return "mix_offset must be > 0 dB";
-	k.crossmix_factor = 1.0 / mix_amp;
-	k.damping = 1.0 - (c.loss_factor / 100.0);
-
-	const double mouth_ap = (nyquist - c.mouth_coefficient) / nyquist;
-	k.mouth_b0_refl = 1.0 - std::fabs(mouth_ap); // ReflectionFilter.h:55-60
-	k.mouth_a1_refl = -mouth_ap;
-	k.mouth_a_rad = mouth_ap;                    // RadiationFilter.h:54-61: b0 = a, b1 = a1 = -a
-	const double nose_ap = (nyquist - c.nose_coefficient) / nyquist;
-	k.nose_b0_refl = 1.0 - std::fabs(nose_ap);
-	k.nose_a1_refl = -nose_ap;
-	k.nose_a_rad = nose_ap;
-
-	// initializeNasalCavity (vtm/VocalTractModel0.h:457-470)
-	k.nasal_k[0] = 0.0;
-	for (int i = 1; i < 5; ++i) k.nasal_k[i] = junction(nasal[i], nasal[i + 1]);
-	k.nasal_k[5] = junction(nasal[5], aperture);
-	k.aperture_radius2 = aperture * aperture;
-	k.nasal_r2_sq = nasal[1] * nasal[1];
-
-	// Throat (vtm/Throat.h:52-60)
-	k.throat_b0 = (c.throat_cutoff * 2.0) / static_cast<double>(k.sample_rate);
-	k.throat_a1 = k.throat_b0 - 1.0;
-	k.throat_gain = amplitude_60db(c.throat_volume);
-	k.bp_T = 1.0 / static_cast<double>(k.sample_rate);
-
-	// Controller::synthesize (vtm_control_model/Controller.cpp:286-287)
-	k.control_steps = static_cast<unsigned>(std::rint(static_cast<double>(k.sample_rate) / control_rate));
-	if (k.control_steps == 0) return "control_rate above the internal sample rate";
-	k.interp_coef = 1.0f / k.control_steps;
-
-	// SampleRateConverter::initializeConversion (vtm/SampleRateConverter.h:136-164)
-	k.src_ratio = c.output_rate / static_cast<double>(k.sample_rate);
-	k.time_inc = static_cast<unsigned>(std::rint(std::pow(2.0, 16) / k.src_ratio));
-	if (k.time_inc == 0) return "output_rate too high for the 16.16 time register";
-	const double rounded_ratio = std::pow(2.0, 16) / k.time_inc;
-	k.upsampling = k.src_ratio >= 1.0;
-	if (k.upsampling) {
-		k.phase_inc = 0;
-		k.pad = kSrcZeroCrossings;
-	} else {
-		k.phase_inc = static_cast<unsigned>(std::rint(k.src_ratio * 65536));
-		k.pad = static_cast<int>(kSrcZeroCrossings / rounded_ratio) + 1;
-	}
-	if (k.pad > kMaxPad || (k.phase_inc == 0 && !k.upsampling)) {
-		err << "output_rate / internal rate = " << k.src_ratio << " is below the supported down-sampling range";
-		return err.str();
-	}
-
-	design_wavetable(c, k, out.wavetable);
-	out.fir = design_glottal_fir();
-	k.fir_taps = static_cast<int>(out.fir.size());
-	if (k.fir_taps > kMaxFirTaps || k.fir_taps > 49) return "glottal FIR longer than the device pre-roll (49 taps)";
-	design_src_filter(out.src_h, out.src_dh);
+	Tables<double> tb;
+	const std::string msg = design_numbers<double>(c, control_rate, k, tb);
+	if (!msg.empty()) return msg;
+	out.fir = tb.fir; out.src_h = tb.src_h; out.src_dh = tb.src_dh; out.wavetable = tb.wavetable;
 	return "";
 }
 

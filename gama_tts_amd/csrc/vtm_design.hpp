@@ -65,6 +65,9 @@ struct Design {
 	std::vector<double> src_h;      // 3328
 	std::vector<double> src_dh;     // 3328
 	std::vector<double> wavetable;  // 512
+	// GVTM_PRECISION_F32: the tables as designed in float (the double vectors above hold the same values widened)
+	bool f32 = false;
+	std::vector<float> fir_f, src_h_f, src_dh_f, wavetable_f;
 };
 
 // Returns "" on success, otherwise a description of the offending value.

@@ -76,7 +76,7 @@ static hipError_t launch_v1(const SynthArgs& args, size_t batch, size_t lds, hip
 
 // generation-2 geometry: utterances per workgroup (DPP rows), chunk length, helper wavefronts,
 // internal-rate ring length
-template <bool MIXED, int U_, int D_ = 1>
+template <typename CT, typename ST, int U_, int D_ = 1>
 struct V2Shape {
 	static constexpr int U = U_;
 	// chunk length: a multiple of 4 (scan blocks) and of the tube unroll (2 for SectionDelay 1, D for
@@ -87,12 +87,12 @@ struct V2Shape {
 	static constexpr int XR = 512;
 };
 
-template <typename ST, int D, int U, int LAYOUT = 0>
+template <typename CT, typename ST, int D, int U, int LAYOUT = 0>
 static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
-	using S = V2Shape<sizeof(ST) == 4, U, D>;
-	auto fn = v2::vtm_synth_kernel<ST, D, S::U, S::C, S::NH, S::XR, LAYOUT>;
-	const size_t lds = v2::smem_bytes<ST, S::U, S::C, S::XR>();
+	using S = V2Shape<CT, ST, U, D>;
+	auto fn = v2::vtm_synth_kernel<CT, ST, D, S::U, S::C, S::NH, S::XR, LAYOUT>;
+	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C, S::XR>();
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
 	if (e != hipSuccess) return e;
@@ -107,55 +107,71 @@ hipError_t launch_dpp_selftest(int* d_out, hipStream_t stream)
 	return hipGetLastError();
 }
 
-int synth_rows(bool mixed, size_t batch, int requested)
+int synth_rows(int precision, size_t batch, int requested)
 {
 	// utterances per workgroup = DPP rows used by the serial wavefronts.  One row keeps the most
 	// workgroups in flight (best latency for small batches); more rows amortise the serial
 	// instruction streams once there are more utterances than compute units.
-	const int max_rows = mixed ? 4 : 2; // fp64 resampler tables leave LDS for two rows only
+	const int max_rows = precision == GVTM_PRECISION_F64 ? 2 : 4; // fp64 resampler tables leave LDS for two rows only
 	int rows = requested;
-	(void) batch;
 	if (rows != 1 && rows != 2 && rows != 4) {
 		rows = batch > 512 ? 4 : (batch > 256 ? 2 : 1);
 	}
 	return rows > max_rows ? max_rows : rows;
 }
 
-template <typename ST, int U>
+template <typename CT, typename ST, int U>
 static size_t v2_lds()
 {
-	using S = V2Shape<sizeof(ST) == 4, U>;
-	return v2::smem_bytes<ST, S::U, S::C, S::XR>();
+	using S = V2Shape<CT, ST, U>;
+	return v2::smem_bytes<CT, ST, S::U, S::C, S::XR>();
 }
 
-size_t synth_lds_bytes(bool mixed, int generation, int rows)
+template <typename CT, typename ST>
+static size_t v2_lds_rows(int rows)
 {
-	if (generation == 1) return v1::synth_lds_bytes(mixed);
-	if (mixed) return rows == 4 ? v2_lds<float, 4>() : (rows == 2 ? v2_lds<float, 2>() : v2_lds<float, 1>());
-	return rows == 2 ? v2_lds<double, 2>() : v2_lds<double, 1>();
+	return rows == 4 ? v2_lds<CT, ST, 4>() : (rows == 2 ? v2_lds<CT, ST, 2>() : v2_lds<CT, ST, 1>());
 }
 
-template <typename ST, int U>
+size_t synth_lds_bytes(int precision, int generation, int rows)
+{
+	if (generation == 1) return v1::synth_lds_bytes(precision == GVTM_PRECISION_MIXED);
+	if (precision == GVTM_PRECISION_F32) return v2_lds_rows<float, float>(rows);
+	if (precision == GVTM_PRECISION_MIXED) return v2_lds_rows<double, float>(rows);
+	return rows == 2 ? v2_lds<double, double, 2>() : v2_lds<double, double, 1>();
+}
+
+template <typename CT, typename ST, int U>
 static hipError_t launch_v2_d(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
 	if (args.k.layout == 1) {
 		// VocalTractModel4: 48 section lanes = one utterance per tube wavefront, SectionDelay 1 only
 		if (args.k.section_delay != 1) return hipErrorInvalidValue;
-		return launch_v2<ST, 1, 1, 1>(args, batch, stream);
+		return launch_v2<CT, ST, 1, 1, 1>(args, batch, stream);
 	}
 	switch (args.k.section_delay) {
-	case 1: return launch_v2<ST, 1, U>(args, batch, stream);
-	case 2: return launch_v2<ST, 2, U>(args, batch, stream);
-	case 3: return launch_v2<ST, 3, U>(args, batch, stream);
-	case 4: return launch_v2<ST, 4, U>(args, batch, stream);
+	case 1: return launch_v2<CT, ST, 1, U>(args, batch, stream);
+	case 2: return launch_v2<CT, ST, 2, U>(args, batch, stream);
+	case 3: return launch_v2<CT, ST, 3, U>(args, batch, stream);
+	case 4: return launch_v2<CT, ST, 4, U>(args, batch, stream);
 	}
 	return hipErrorInvalidValue;
 }
 
-hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, int rows, hipStream_t stream)
+template <typename CT, typename ST>
+static hipError_t launch_v2_rows(const SynthArgs& args, size_t batch, int rows, hipStream_t stream)
+{
+	if (rows == 4) return launch_v2_d<CT, ST, 4>(args, batch, stream);
+	if (rows == 2) return launch_v2_d<CT, ST, 2>(args, batch, stream);
+	return launch_v2_d<CT, ST, 1>(args, batch, stream);
+}
+
+hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int generation, int rows, hipStream_t stream)
 {
 	const int d = args.k.section_delay;
+	const bool mixed = precision == GVTM_PRECISION_MIXED;
 	if (generation == 1) {
+		if (precision == GVTM_PRECISION_F32) return hipErrorInvalidValue; // the round-1 baseline kernel is fp64 / mixed only
 		const size_t lds = v1::synth_lds_bytes(mixed);
 		if (mixed) {
 			switch (d) {
@@ -174,13 +190,33 @@ hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int gen
 		}
 		return hipErrorInvalidValue;
 	}
-	if (mixed) {
-		if (rows == 4) return launch_v2_d<float, 4>(args, batch, stream);
-		if (rows == 2) return launch_v2_d<float, 2>(args, batch, stream);
-		return launch_v2_d<float, 1>(args, batch, stream);
+	if (precision == GVTM_PRECISION_F32) return launch_v2_rows<float, float>(args, batch, rows, stream);
+	if (mixed) return launch_v2_rows<double, float>(args, batch, rows, stream);
+	if (rows == 2) return launch_v2_d<double, double, 2>(args, batch, stream);
+	return launch_v2_d<double, double, 1>(args, batch, stream);
+}
+
+// Test hook: the all-float path's per-step conversions evaluated ON THE DEVICE
+// (kind 0 = Util::frequency, 1 = Util::amplitude60dB, 2 = tanf stand-in, 3 = cosf stand-in)
+__global__ void float_math_probe_kernel(int kind, const float* x, size_t n, float* out)
+{
+	const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float v = x[i];
+	float r = 0.0f;
+	switch (kind) {
+	case 0: r = frequency_dev(v); break;
+	case 1: r = amplitude_60db_dev(v); break;
+	case 2: r = tan_dev(v); break;
+	case 3: r = cos_dev(v); break;
 	}
-	if (rows == 2) return launch_v2_d<double, 2>(args, batch, stream);
-	return launch_v2_d<double, 1>(args, batch, stream);
+	out[i] = r;
+}
+
+hipError_t launch_float_math_probe(int kind, const float* d_x, size_t n, float* d_out, hipStream_t stream)
+{
+	hipLaunchKernelGGL(float_math_probe_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, kind, d_x, n, d_out);
+	return hipGetLastError();
 }
 
 hipError_t launch_normalize(const NormalizeArgs& args, size_t batch, hipStream_t stream)

@@ -22,10 +22,10 @@ struct SynthArgs {
 	float* audio;                // [batch][audio_stride]
 	int64_t* out_counts;         // [batch] or null
 	float* maxabs;               // [batch] or null
-	const double* wavetable;     // [512]
-	const double* fir;           // [fir_taps]
-	const double* src_h;         // [3328]
-	const double* src_dh;        // [3328]
+	const void* wavetable;       // [512]      design tables: double, or float for GVTM_PRECISION_F32
+	const void* fir;             // [fir_taps]
+	const void* src_h;           // [3328]
+	const void* src_dh;          // [3328]
 	size_t max_frames;
 	size_t audio_stride;
 	size_t batch;
@@ -46,10 +46,13 @@ struct NormalizeArgs {
 // generation: 1 = phase-alternating baseline, 2 = wave-specialised pipeline (default)
 // rows: utterances per workgroup for generation 2 (1, 2 or 4); synth_rows() picks it from the
 // batch size unless `requested` names one
-int synth_rows(bool mixed, size_t batch, int requested);
-size_t synth_lds_bytes(bool mixed, int generation, int rows);
-hipError_t launch_synth(const SynthArgs& args, size_t batch, bool mixed, int generation, int rows, hipStream_t stream);
-hipError_t launch_dpp_selftest(int* d_out /* [384] */, hipStream_t stream);
+// precision: gvtm_precision (GVTM_PRECISION_F32 runs on generation 2 only)
+int synth_rows(int precision, size_t batch, int requested);
+size_t synth_lds_bytes(int precision, int generation, int rows);
+hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int generation, int rows, hipStream_t stream);
+constexpr int kDppSelftestInts = 640;
+hipError_t launch_dpp_selftest(int* d_out /* [kDppSelftestInts] */, hipStream_t stream);
+hipError_t launch_float_math_probe(int kind, const float* d_x, size_t n, float* d_out, hipStream_t stream);
 hipError_t launch_normalize(const NormalizeArgs& args, size_t batch, hipStream_t stream);
 
 } // namespace gvtm

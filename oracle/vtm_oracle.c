@@ -44,6 +44,17 @@ void vtmo_noise_sequence(double* lp_noise, size_t count)
 	}
 }
 
+/* This machine's libm, vectorised: lets the tests pin the product's restatement of glibc's powf
+ * (gama_tts_amd/csrc/vtm_math.hpp) over whole argument ranges. */
+void vtmo_libm_powf(float base, const float* x, size_t n, float* out)
+{
+	for (size_t i = 0; i < n; ++i) out[i] = powf(base, x[i]);
+}
+void vtmo_libm_tanf_cosf(int which, const float* x, size_t n, float* out)
+{
+	for (size_t i = 0; i < n; ++i) out[i] = which ? cosf(x[i]) : tanf(x[i]);
+}
+
 int vtmo_fir_coefficients(double* coef) { return vtmo_fir_coefficients_f64(coef); }
 void vtmo_src_filter(double* h, double* delta_h) { vtmo_src_filter_f64(h, delta_h); }
 void vtmo_wavetable(const vtmo_config* cfg, int sample_rate, double* table) { vtmo_wavetable_f64(cfg, sample_rate, table); }

@@ -118,6 +118,10 @@ size_t vtmo_synthesize_batch(const vtmo_config* cfg, double control_rate,
 		const float* params, size_t batch, size_t n_frames,
 		float* out, size_t out_stride);
 
+/* libm of this machine over an array (powf(base, x[i]); tanf / cosf for which = 0 / 1) */
+void vtmo_libm_powf(float base, const float* x, size_t n, float* out);
+void vtmo_libm_tanf_cosf(int which, const float* x, size_t n, float* out);
+
 /* Util::calculateOutputScale (VTMUtil.cpp:48-67): 0.95/max|x|, 0 if max < 1e-30. */
 float vtmo_output_scale(const float* x, size_t n);
 

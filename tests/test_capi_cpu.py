@@ -52,6 +52,32 @@ def test_design_matches_oracle_bit_for_bit(delay, rate, layout):
         assert plan.output_count(frames) == oracle.output_count(ocfg, frames)
 
 
+@pytest.mark.parametrize("delay,rate,layout", [(1, 44100.0, 0), (2, 48000.0, 0), (3, 44100.0, 0), (1, 16000.0, 0), (1, 44100.0, 1)])
+def test_float_design_matches_float_oracle_bit_for_bit(delay, rate, layout):
+    """GVTM_PRECISION_F32 designs every constant and table in float, as the reference's TFloat = float models do."""
+    d = g.read_config_file(oracle.VOICE_MALE)
+    plan = g.Plan(g.config_from_dict(d, rate, delay, capi.PRECISION_F32, layout), 250.0, capi.DEVICE_NONE)
+    ocfg = oracle.male_config(rate, delay, layout, float_model=1)
+    od = oracle.derive(ocfg)
+    i = plan.info
+    assert i.precision == capi.PRECISION_F32
+    assert (i.internal_sample_rate, i.control_steps, i.fir_taps) == (od.sample_rate, od.control_steps, od.fir_taps)
+    assert i.fir_taps == 47  # SURVEY.md section 8 a9: 49 taps in double, 47 in float
+    assert (i.time_register_increment, i.phase_increment, i.pad_size, i.upsampling) == \
+        (od.time_register_increment, od.phase_increment, od.pad_size, od.upsampling)
+    fir = np.empty(401, dtype=np.float32)
+    n = oracle.lib().vtmo_fir_coefficients_f32(fir.ctypes.data)
+    h, dh, wt = np.empty(3328, dtype=np.float32), np.empty(3328, dtype=np.float32), np.empty(512, dtype=np.float32)
+    oracle.lib().vtmo_src_filter_f32(h.ctypes.data, dh.ctypes.data)
+    oracle.lib().vtmo_wavetable_f32(ctypes.byref(ocfg), od.sample_rate, wt.ctypes.data)
+    assert np.array_equal(plan.table(capi.TABLE_FIR), fir[:n].astype(np.float64))
+    assert np.array_equal(plan.table(capi.TABLE_SRC_H), h.astype(np.float64))
+    assert np.array_equal(plan.table(capi.TABLE_SRC_DH), dh.astype(np.float64))
+    assert np.array_equal(plan.table(capi.TABLE_WAVETABLE), wt.astype(np.float64))
+    for frames in (0, 1, 3, 100, 500, 7500):
+        assert plan.output_count(frames) == oracle.output_count(ocfg, frames)
+
+
 def test_output_count_sweep_against_oracle_ring_logic():
     """Closed form vs the literal ring-buffer walk, incl. the down-sampling flush overrun
     (SampleRateConverter.h:298-308) that the product refuses instead of reproducing."""
@@ -149,3 +175,68 @@ def test_short_math_accuracy():
         small = ~ok & np.isfinite(ref64)
         if small.any():
             assert float(np.abs(out[small].astype(np.longdouble) - ref[small]).max()) < 4e-16
+
+
+def test_powf_restatement_is_bit_identical_to_libm():
+    """The all-float path reproduces glibc's powf(2, x) / powf(10, y) (csrc/vtm_math.hpp): every float in
+    the ranges the model can produce (pitch -> |x| < 8; dB -> -3 <= y < 0), plus wider samples."""
+    lib = g.load_library()
+    lib.gvtm_debug_short_math.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    ol = oracle.lib()
+    ol.vtmo_libm_powf.argtypes = [ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+
+    def all_floats(lo, hi):
+        a = np.array([lo, hi], dtype=np.float32).view(np.uint32)
+        return np.arange(a[0], a[1] + 1, dtype=np.uint32).view(np.float32)
+
+    def check(kind, base, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        ref = np.empty_like(x)
+        ol.vtmo_libm_powf(base, x.ctypes.data, x.size, ref.ctypes.data)
+        xd = x.astype(np.float64)
+        out = np.empty_like(xd)
+        assert lib.gvtm_debug_short_math(kind, xd.ctypes.data, xd.size, out.ctypes.data) == 0
+        assert np.array_equal(out.astype(np.float32).view(np.uint32), ref.view(np.uint32)), (kind, base)
+
+    # 10^y: every float y in [-3.25, -2^-10] (dB 0..60 -> y in [-3, 0))
+    check(5, 10.0, -all_floats(2.0 ** -10, 3.25))
+    # 2^x: every float in +-[2^-6, 8] (pitch -99..+93 semitones)
+    pos = all_floats(2.0 ** -6, 8.0)
+    check(4, 2.0, pos)
+    check(4, 2.0, -pos)
+    rng = np.random.default_rng(11)
+    check(4, 2.0, rng.uniform(-90.0, 90.0, 400000))
+    check(5, 10.0, rng.uniform(-25.0, 25.0, 400000))
+    check(4, 2.0, np.array([0.0, -0.0, 1e-30, -1e-30, 1.0, -1.0, 0.25], dtype=np.float32))
+
+
+def test_cosf_tanf_restatement_is_bit_identical_to_libm():
+    """glibc's cosf / tanf as the all-float band-pass design needs them (csrc/vtm_math.hpp): every float of
+    cos on [2^-13, 3.2] and tan on [2^-14, 1.38] (bandwidth up to 0.44 of the internal rate)."""
+    lib = g.load_library()
+    lib.gvtm_debug_short_math.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    ol = oracle.lib()
+    ol.vtmo_libm_tanf_cosf.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+
+    def check(kind, which, lo, hi):
+        a = np.array([lo, hi], dtype=np.float32).view(np.uint32)
+        step = 1 << 22
+        for start in range(int(a[0]), int(a[1]) + 1, step):
+            x = np.arange(start, min(start + step, int(a[1]) + 1), dtype=np.uint32).view(np.float32)
+            ref = np.empty_like(x)
+            ol.vtmo_libm_tanf_cosf(which, x.ctypes.data, x.size, ref.ctypes.data)
+            xd = x.astype(np.float64)
+            out = np.empty_like(xd)
+            assert lib.gvtm_debug_short_math(kind, xd.ctypes.data, xd.size, out.ctypes.data) == 0
+            assert np.array_equal(out.astype(np.float32).view(np.uint32), ref.view(np.uint32)), (kind, start)
+
+    check(6, 1, 2.0 ** -13, 3.2)
+    check(7, 0, 2.0 ** -14, 1.38)
+    for kind, which in ((6, 1), (7, 0)):  # zero, and arguments outside the restated ranges (library path)
+        x = np.array([0.0, 1e-30, 5.0, 100.0, 1000.0, -0.5], dtype=np.float32)
+        ref = np.empty_like(x)
+        ol.vtmo_libm_tanf_cosf(which, x.ctypes.data, x.size, ref.ctypes.data)
+        xd = x.astype(np.float64)
+        out = np.empty_like(xd)
+        assert lib.gvtm_debug_short_math(kind, xd.ctypes.data, xd.size, out.ctypes.data) == 0
+        assert np.allclose(out, ref, rtol=3e-7, atol=0)

@@ -37,7 +37,7 @@ def _peak_err(got, ref):
 
 @pytest.mark.parametrize("precision,tol", [(capi.PRECISION_F64, TOL_F64), (capi.PRECISION_MIXED, TOL_MIXED)],
                          ids=["f64", "mixed"])
-@pytest.mark.parametrize("case", golden_cases.CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in golden_cases.CASES if not c.get("float_model")], ids=lambda c: c["name"])
 def test_reference_vectors(case, precision, tol, golden):
     m = golden["manifest"][case["name"]]
     tr = golden_cases.track_for(case, golden)

@@ -34,10 +34,20 @@ taps = d_taps.cpu().numpy()
 audio = d_audio.cpu().numpy()
 names = ["u", "sig", "thr", "fir", "lpnoise", "pos0", "pos1", "x"]
 for b in range(2):
-    ref_audio, ref_taps = oracle.synthesize_debug(oracle.male_config(44100.0, delay, layout), params[b])
+    ref_audio, ref_taps = oracle.synthesize_debug(oracle.male_config(44100.0, delay, layout, float_model=int(prec == 2)), params[b])
     for i, nm in enumerate(names):
         d = np.abs(taps[b, :, i] - ref_taps[:, i])
         first = int(np.argmax(d > 1e-9 * max(1e-30, np.abs(ref_taps[:, i]).max()))) if d.max() > 0 else -1
-        print("utt %d %-8s max|ref| %.3e  max|diff| %.3e  first-bad-step %d" % (b, nm, np.abs(ref_taps[:, i]).max(), d.max(), first))
+        exact = float((taps[b, :, i] == ref_taps[:, i]).mean())
+        print("utt %d %-8s max|ref| %.3e  max|diff| %.3e  first-bad-step %d  bit-identical %.4f" % (b, nm, np.abs(ref_taps[:, i]).max(), d.max(), first, exact))
     e = np.abs(audio[b].astype(np.float64) - ref_audio)
     print("utt %d audio   max|ref| %.3e  max|diff| %.3e first-bad %d" % (b, np.abs(ref_audio).max(), e.max(), int(np.argmax(e > 1e-9))))
+if len(sys.argv) > 5:
+    b = 0
+    ref_audio, ref_taps = oracle.synthesize_debug(oracle.male_config(44100.0, delay, layout, float_model=int(prec == 2)), params[b])
+    np.set_printoptions(precision=10, linewidth=200)
+    for i, nm in enumerate(names):
+        bad = np.nonzero(taps[b, :, i] != ref_taps[:, i])[0][:6]
+        print(nm, "first mismatching steps", bad.tolist())
+        for s in bad[:3]:
+            print("   step %d dev %r ref %r" % (s, float(taps[b, s, i]).hex(), float(ref_taps[s, i]).hex()))
