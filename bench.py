@@ -30,7 +30,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(params, output_rate, delay, budget_s=12.0):
+def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False):
     """Single-thread CPU throughput (output samples/s) on a bounded sample of the workload."""
     import numpy as np
     import oracle
@@ -49,6 +49,8 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0):
     elif oracle.ref_binary("o3"):
         exe_kind = "o3"
     model = {1: "0", 2: "2:2", 3: "3", 4: "2:4"}[delay]
+    if float_model:  # the reference's TFloat = float classes
+        model = {1: "1", 2: "2f:2", 3: "2f:3", 4: "2f:4"}[delay]
     if exe_kind:
         kind = "reference"
         _, info = oracle.ref_synthesize(sample[0], model, output_rate, 250.0, kind=exe_kind, repeat=2)
@@ -64,7 +66,7 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0):
             len(sample), repeat, sample.shape[1], exe_kind, model)
     else:
         kind = "port"
-        cfg = oracle.male_config(output_rate, delay)
+        cfg = oracle.male_config(output_rate, delay, float_model=int(float_model))
         t0 = time.perf_counter()
         out = oracle.synthesize(cfg, sample[0])
         per = time.perf_counter() - t0
@@ -87,7 +89,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=500, help="control frames per utterance (4 ms each)")
     ap.add_argument("--delay", type=int, default=1, help="SectionDelay (1 = VocalTractModel0)")
-    ap.add_argument("--precision", choices=["f64", "mixed"], default="f64")
+    ap.add_argument("--precision", choices=["f64", "mixed", "f32"], default="f64",
+                    help="f64 = VocalTractModel0<double> semantics (default); f32 = VocalTractModel0<float> (reference model 1); "
+                         "mixed = fp64 with an fp32 resampler")
     ap.add_argument("--output-rate", type=float, default=44100.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
@@ -123,7 +127,7 @@ def main():
 
     voice = os.path.join(ROOT, "tests", "golden", "voice_male.txt")
     cfgd = g.read_config_file(voice)
-    prec = capi.PRECISION_F64 if args.precision == "f64" else capi.PRECISION_MIXED
+    prec = {"f64": capi.PRECISION_F64, "mixed": capi.PRECISION_MIXED, "f32": capi.PRECISION_F32}[args.precision]
     plan = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay, prec), 250.0, local_rank)
     n_out = plan.output_count(args.frames)
 
@@ -194,10 +198,10 @@ def main():
             "data": "synthetic",
             "real_time_factor": value / args.output_rate,
             "config": {
-                "workload": "batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel%s "
+                "workload": "batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel%s<%s> "
                             "semantics (SectionDelay %d), male voice, %.0f Hz out" % (
                                 args.batch, args.frames, args.frames * 0.004, "0" if args.delay == 1 else "2",
-                                args.delay, args.output_rate),
+                                "float" if args.precision == "f32" else "double", args.delay, args.output_rate),
                 "batch_per_gpu": args.batch,
                 "frames": args.frames,
                 "samples_per_utterance": n_out,
@@ -218,7 +222,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay)
+            line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=args.precision == "f32")
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
