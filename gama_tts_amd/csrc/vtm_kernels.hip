@@ -79,12 +79,31 @@ static hipError_t launch_v1(const SynthArgs& args, size_t batch, size_t lds, hip
 template <typename CT, typename ST, int U_, int D_ = 1>
 struct V2Shape {
 	static constexpr int U = U_;
-	// chunk length: a multiple of 4 (scan blocks) and of the tube unroll (2 for SectionDelay 1, D for
-	// even D, 6 for 3), i.e. of 12; at most 64 so that a stage is one pass when U = 1 (60 also avoids
-	// the power-of-two LDS strides of 64, measured 4% slower); LDS caps U * C
-	static constexpr int C = (U_ == 1) ? 60 : 24;
-	static constexpr int NH = (U_ == 1) ? 3 : 7; // 8 resp. 12 wavefronts per workgroup
-	static constexpr int XR = 512;
+	// Chunk length C: a multiple of 4 (scan blocks) and of the tube unroll (2 for SectionDelay 1, D for
+	// even D, 6 for 3), i.e. of 12.
+	//   U = 1: the tick time is the tube wavefront's, whatever C (60 = one helper pass per stage, and no
+	//          power-of-two LDS strides, measured 4 % faster than 64).
+	//   U > 1: every tick has fixed costs (barrier, stage prologues, ticket traffic, partly filled 64-item
+	//          passes), so the longest chunk LDS allows wins: measured on batch 4096 in float, C = 24 / 36 / 48
+	//          -> 24.8 / 21.6 / 18.4 ms; batch 512, C = 24 / 48 / 96 -> 4.71 / 4.64 / 4.38 ms.
+	// LDS per workgroup (KB): float 1x60 65, 2x96 143, 4x48 144; mixed 1x60 94, 2x48 131, 4x24 138;
+	// fp64 1x60 122, 2x36 139.
+	static constexpr bool kAllFloat = sizeof(CT) == 4;
+	static constexpr bool kMixed = sizeof(CT) == 8 && sizeof(ST) == 4;
+#ifdef GVTM_TUNE_C1
+	static constexpr int C = (U_ == 1) ? GVTM_TUNE_C1 : (U_ == 2 ? GVTM_TUNE_C2 : GVTM_TUNE_C4);
+#else
+	static constexpr int C = (U_ == 1) ? 60 : (U_ == 2 ? (kAllFloat ? 96 : (kMixed ? 48 : 36)) : (kAllFloat ? 48 : 24));
+#endif
+#ifndef GVTM_TUNE_NH_MULTI
+#define GVTM_TUNE_NH_MULTI 7
+#endif
+#ifndef GVTM_TUNE_NH_SINGLE
+#define GVTM_TUNE_NH_SINGLE 3
+#endif
+	static constexpr int NH = (U_ == 1) ? GVTM_TUNE_NH_SINGLE : GVTM_TUNE_NH_MULTI; // 8 resp. 12 wavefronts per workgroup
+	// internal-rate ring: two chunks + resampler history + flush zeros, a power of two
+	static constexpr int XR = (2 * C + 4 * kMaxPad <= 512) ? 512 : 1024;
 };
 
 template <typename CT, typename ST, int D, int U, int LAYOUT = 0>
