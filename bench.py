@@ -94,6 +94,7 @@ def main():
                          "mixed = fp64 with an fp32 resampler")
     ap.add_argument("--output-rate", type=float, default=44100.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (other precision, batch 4096)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -221,6 +222,34 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
+        if world == 1 and not args.no_extras:
+            # the same kernel in the other arithmetic (BASELINE configs[1] names fp32, configs[3] an fp32/fp64
+            # sweep) and at the batch BASELINE's target is quoted on; short runs, reported beside the headline
+            def extra(precision, batch):
+                pl = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay,
+                                               {"f64": capi.PRECISION_F64, "mixed": capi.PRECISION_MIXED, "f32": capi.PRECISION_F32}[precision]),
+                            250.0, local_rank)
+                reps_e = (batch + pool - 1) // pool
+                dp = d_pool.repeat((reps_e, 1, 1))[:batch].contiguous()
+                da = torch.empty((batch, n_out), dtype=torch.float32, device=dev)
+                dc = torch.zeros(batch, dtype=torch.int64, device=dev)
+                for _ in range(2):
+                    pl.synthesize_device(dp, batch, args.frames, da, n_out, None, dc, None, stream)
+                torch.cuda.synchronize()
+                pl.set_timing(True)
+                t_e = time.perf_counter()
+                n_e = 5
+                for _ in range(n_e):
+                    pl.synthesize_device(dp, batch, args.frames, da, n_out, None, dc, None, stream)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t_e
+                kms, _ = pl.take_kernel_ms()
+                assert int(dc.min().item()) == n_out
+                del da, dp
+                return {"precision": precision, "batch": batch, "value": float(n_out) * batch * n_e / el, "unit": "samples/s",
+                        "kernel_ms": kms, "real_time_factor": float(n_out) * batch * n_e / el / args.output_rate}
+            other = "f32" if args.precision != "f32" else "f64"
+            line["extras"] = [extra(other, args.batch), extra(args.precision, 4096), extra(other, 4096)]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=args.precision == "f32")
         print(json.dumps(line), flush=True)

@@ -50,11 +50,12 @@ gvtm_config config_from_keys(const std::map<std::string, std::string>& k, int pr
 	const int model = k.count("model") ? static_cast<int>(num(k, "model")) : 0;
 	switch (model) {
 	case 0: case 2: c.section_delay = 1; break;
+	case 1: c.section_delay = 1; precision = GVTM_PRECISION_F32; break; // VocalTractModel0<float> (VocalTractModel.cpp:45-46)
 	case 3: c.section_delay = 3; break;
 	case 4: c.section_delay = 1; c.tube_layout = GVTM_TUBE_30_18; break;
 	default:
 		throw std::runtime_error("vocal tract model " + std::to_string(model) +
-				" is not served by the device path (supported: 0, 2, 3, 4)");
+				" is not served by the device path (supported: 0, 1, 2, 3, 4)");
 	}
 	if (k.count("section_delay")) c.section_delay = static_cast<int>(num(k, "section_delay"));
 	c.precision = precision;

@@ -23,10 +23,11 @@ int main(int argc, char** argv)
 	for (; i < argc && argv[i][0] == '-'; ++i) {
 		if (std::strcmp(argv[i], "-d") == 0 && i + 1 < argc) device = std::atoi(argv[++i]);
 		else if (std::strcmp(argv[i], "-m") == 0) precision = GVTM_PRECISION_MIXED;
+		else if (std::strcmp(argv[i], "-f") == 0) precision = GVTM_PRECISION_F32; // reference model 1 (float) semantics
 		else { std::cerr << "unknown option " << argv[i] << std::endl; return EXIT_FAILURE; }
 	}
 	if (argc - i < 3) {
-		std::cerr << "usage: " << argv[0] << " [-d device] [-m] voice_dir out_dir param_file..." << std::endl;
+		std::cerr << "usage: " << argv[0] << " [-d device] [-m | -f] voice_dir out_dir param_file..." << std::endl;
 		return EXIT_FAILURE;
 	}
 	try {

@@ -93,7 +93,8 @@ public:
 		for (int i = 0; i < 8; ++i) c.radius_coef[i] = k.number(coef_keys[i]);
 		c.section_delay = k.has("section_delay") ? k.integer("section_delay") : 1;
 		c.tube_layout = k.has("tube_layout") ? k.integer("tube_layout") : GVTM_TUBE_10_6;
-		c.precision = k.text("gpu_precision", "f64") == "mixed" ? GVTM_PRECISION_MIXED : GVTM_PRECISION_F64;
+		const std::string prec = k.text("gpu_precision", "f64");
+		c.precision = prec == "mixed" ? GVTM_PRECISION_MIXED : (prec == "f32" ? GVTM_PRECISION_F32 : GVTM_PRECISION_F64);
 		const int device = k.has("gpu_device") ? k.integer("gpu_device") : 0;
 
 		// The host interpolates the control frames itself (Controller.cpp:294-311) and hands over

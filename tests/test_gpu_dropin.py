@@ -34,6 +34,24 @@ def test_plugin_through_reference_loader(name, golden, tmp_path):
     assert err <= 1e-9, err
 
 
+@pytest.mark.skipif(oracle.ref_binary() is None, reason="oracle/_ref/ref_vtm (the compiled reference) not present")
+def test_plugin_float_model_through_reference_loader(golden, tmp_path):
+    """`gpu_precision = f32` makes the plugin stand in for model 1 (VocalTractModel0<float>)."""
+    keys = oracle.read_config_file(oracle.VOICE_MALE)
+    keys["gpu_precision"] = "f32"
+    cfg = str(tmp_path / "vtm1.txt")
+    with open(cfg, "w") as f:
+        for k, v in keys.items():
+            f.write("%s = %s\n" % (k, v))
+    import golden_cases
+    case = next(c for c in golden_cases.CASES if c["name"] == "rand5_m1")
+    tr = golden_cases.track_for(case, golden)
+    out, info = oracle.ref_synthesize(tr, "2000:" + PLUGIN, config=cfg, tmpdir=str(tmp_path))
+    ref = golden["rand5_m1__out"]
+    assert out.size == ref.size and float(info["fs"]) == 20034.0
+    assert np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max() <= 1e-6
+
+
 def test_plugin_thirty_section_tube_through_reference_loader(golden, tmp_path):
     """`tube_layout = 1` in vtm.txt makes the plugin stand in for model 4 (VocalTractModel4)."""
     keys = oracle.read_config_file(oracle.VOICE_MALE)
@@ -80,7 +98,7 @@ def _read_wav(path):
     return fmt, np.frombuffer(data[44:44 + n], dtype="<i2")
 
 
-@pytest.mark.parametrize("model,layout", [("0", 0), ("4", 1)])
+@pytest.mark.parametrize("model,layout", [("0", 0), ("4", 1), ("1", 0)])
 def test_batched_vtm_cli_writes_reference_wavs(model, layout, golden, tmp_path):
     """`gama_vtm_batch voice_dir out_dir a.txt b.txt` == `gama_tts vtm` per file: same frames in,
     same 16-bit samples out (scale 0.95/max, round(x * 32767), WAVEFileWriter.cpp:62-125)."""
@@ -98,7 +116,7 @@ def test_batched_vtm_cli_writes_reference_wavs(model, layout, golden, tmp_path):
         files.append(p)
     r = subprocess.run([CLI, voice, out_dir] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    cfg = oracle.male_config(layout=layout)
+    cfg = oracle.male_config(layout=layout, float_model=int(model == "1"))  # `model = 1` is the float model
     for name, tr in tracks_.items():
         fmt, pcm = _read_wav(os.path.join(out_dir, name + ".wav"))
         assert fmt == (16, 1, 1, 44100, 88200, 2, 16)
