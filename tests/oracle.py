@@ -110,7 +110,7 @@ def lib():
     global _lib
     if _lib is None:
         srcs = [os.path.join(ORACLE_DIR, f) for f in ("vtm_oracle.c", "vtm_oracle_body.inc", "vtm_oracle_f64.c",
-                                                       "vtm_oracle_f32.c", "vtm_oracle.h")]
+                                                       "vtm_oracle_f32.c", "vtm_oracle.h", "vtm_tracks_oracle.c", "vtm_tracks_oracle.h")]
         if (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
             build()
         L = ctypes.CDLL(LIB_PATH)
@@ -141,6 +141,41 @@ def lib():
         L.vtmo_output_scale.restype = ctypes.c_float
         _lib = L
     return _lib
+
+
+class TrackConfig(ctypes.Structure):
+    _fields_ = [("control_period", ctypes.c_int), ("macro_intonation", ctypes.c_int), ("micro_intonation", ctypes.c_int),
+                ("intonation_drift", ctypes.c_int), ("smooth_intonation", ctypes.c_int),
+                ("initial_pitch", ctypes.c_double), ("mean_pitch", ctypes.c_double),
+                ("drift_deviation", ctypes.c_double), ("drift_sample_rate", ctypes.c_double),
+                ("drift_lowpass_cutoff", ctypes.c_double)]
+
+
+def track_config(v):
+    """v: the 10 numbers of a tracks fixture (control_period, macro, micro, drift, smooth, initial_pitch, mean_pitch,
+    drift deviation / sample rate / cutoff)."""
+    c = TrackConfig()
+    c.control_period, c.macro_intonation, c.micro_intonation, c.intonation_drift, c.smooth_intonation = (int(x) for x in v[:5])
+    c.initial_pitch, c.mean_pitch, c.drift_deviation, c.drift_sample_rate, c.drift_lowpass_cutoff = (float(x) for x in v[5:10])
+    return c
+
+
+FRESH_DRIFT = (0.7892347, 0.0, 0.0, 0.0, 0.0)
+
+
+def tracks_generate(cfg, events, drift=FRESH_DRIFT):
+    """events float64 [E][38] -> (frames float32 [F][16], drift state after)   (oracle/vtm_tracks_oracle.c)"""
+    L = lib()
+    L.vtmo_tracks_generate.argtypes = [ctypes.POINTER(TrackConfig), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_size_t]
+    L.vtmo_tracks_generate.restype = ctypes.c_size_t
+    events = np.ascontiguousarray(events, dtype=np.float64)
+    st = np.array(drift, dtype=np.float64)
+    n = L.vtmo_tracks_generate(ctypes.byref(cfg), events.ctypes.data, events.shape[0], st.copy().ctypes.data, None, 0)
+    frames = np.zeros((n, 16), dtype=np.float32)
+    got = L.vtmo_tracks_generate(ctypes.byref(cfg), events.ctypes.data, events.shape[0], st.ctypes.data, frames.ctypes.data, n)
+    assert got == n
+    return frames, tuple(st)
 
 
 def derive(cfg, control_rate=250.0):
