@@ -8,6 +8,7 @@ raises when the native library is missing.
 from .capi import (  # noqa: F401
     GvtmError,
     Plan,
+    TrackConfig,
     config_from_dict,
     device_count,
     library_path,

@@ -116,6 +116,12 @@ def load_library():
     L.gvtm_synthesize_batch_host.restype = i32
     L.gvtm_normalize_batch_device.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.gvtm_normalize_batch_device.restype = i32
+    L.gvtm_tracks_frame_count.argtypes = [ctypes.POINTER(TrackConfig), vp, sz]
+    L.gvtm_tracks_frame_count.restype = sz
+    L.gvtm_generate_tracks_device.argtypes = [i32, ctypes.POINTER(TrackConfig), vp, vp, sz, sz, vp, vp, vp, vp]
+    L.gvtm_generate_tracks_device.restype = i32
+    L.gvtm_generate_tracks_host.argtypes = [i32, ctypes.POINTER(TrackConfig), vp, vp, sz, sz, vp, vp, vp]
+    L.gvtm_generate_tracks_host.restype = i32
     L.gvtm_plan_set_timing.argtypes = [vp, i32]
     L.gvtm_plan_set_timing.restype = i32
     L.gvtm_plan_take_kernel_ms.argtypes = [vp, ctypes.POINTER(i32)]
@@ -161,6 +167,72 @@ def config_from_dict(d, output_rate=None, section_delay=1, precision=PRECISION_F
     c.precision = int(precision)
     c.tube_layout = int(tube_layout)
     return c
+
+
+class TrackConfig(ctypes.Structure):
+    """gvtm_track_config"""
+    _fields_ = [("control_period_ms", ctypes.c_int32), ("macro_intonation", ctypes.c_int32), ("micro_intonation", ctypes.c_int32),
+                ("intonation_drift", ctypes.c_int32), ("smooth_intonation", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+                ("initial_pitch", ctypes.c_double), ("mean_pitch", ctypes.c_double), ("drift_deviation", ctypes.c_double),
+                ("drift_sample_rate", ctypes.c_double), ("drift_lowpass_cutoff", ctypes.c_double)]
+
+
+# gvtm_event / gvtm_drift_state as numpy record layouts (296 and 40 bytes)
+EVENT_DTYPE = np.dtype([("time_ms", "<i4"), ("has_interp", "<i4"), ("interp", "<f8", 4), ("param", "<f8", 16),
+                        ("special", "<f8", 16)])
+DRIFT_DTYPE = np.dtype([("seed", "<f8"), ("x1", "<f8"), ("x2", "<f8"), ("y1", "<f8"), ("y2", "<f8")])
+FRESH_DRIFT = (0.7892347, 0.0, 0.0, 0.0, 0.0)
+
+
+def events_from_table(table):
+    """float64 [E][38] rows (time, has_interp, a, b, c, d, parameters[16], specialParameters[16]) -> gvtm_event records."""
+    table = np.asarray(table, dtype=np.float64)
+    ev = np.zeros(table.shape[0], dtype=EVENT_DTYPE)
+    ev["time_ms"] = table[:, 0].astype(np.int32)
+    ev["has_interp"] = (table[:, 1] != 0).astype(np.int32)
+    ev["interp"] = table[:, 2:6]
+    ev["param"] = table[:, 6:22]
+    ev["special"] = table[:, 22:38]
+    return ev
+
+
+def tracks_frame_count(config, events):
+    lib = load_library()
+    events = np.ascontiguousarray(events, dtype=EVENT_DTYPE)
+    n = lib.gvtm_tracks_frame_count(ctypes.byref(config), _ptr(events), events.shape[0])
+    if n == ctypes.c_size_t(-1).value:
+        raise GvtmError(1, lib.gvtm_last_error().decode())
+    return n
+
+
+def generate_tracks_host(config, event_lists, max_frames, drift=None, device=0):
+    """event_lists: list of gvtm_event record arrays -> (params float32 [B][max_frames][16], frame_counts int32 [B], drift out)."""
+    lib = load_library()
+    batch = len(event_lists)
+    offsets = np.zeros(batch + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(e) for e in event_lists])
+    events = np.concatenate([np.ascontiguousarray(e, dtype=EVENT_DTYPE) for e in event_lists]) if batch else np.zeros(0, EVENT_DTYPE)
+    params = np.zeros((batch, max_frames, 16), dtype=np.float32)
+    counts = np.zeros(batch, dtype=np.int32)
+    dr = None
+    if drift is not None:
+        dr = np.zeros(batch, dtype=DRIFT_DTYPE)
+        for b, st in enumerate(drift):
+            dr[b] = tuple(st)
+    rc = lib.gvtm_generate_tracks_host(int(device), ctypes.byref(config), _ptr(events), _ptr(offsets), batch, int(max_frames),
+                                       _ptr(params), _ptr(counts), _ptr(dr))
+    if rc != 0:
+        raise GvtmError(rc, lib.gvtm_last_error().decode() or lib.gvtm_status_string(rc).decode())
+    return params, counts, dr
+
+
+def generate_tracks_device(config, d_events, d_offsets, batch, max_frames, d_params, d_frame_counts=None, d_drift=None,
+                           stream=None, device=0):
+    lib = load_library()
+    rc = lib.gvtm_generate_tracks_device(int(device), ctypes.byref(config), _ptr(d_events), _ptr(d_offsets), int(batch),
+                                         int(max_frames), _ptr(d_params), _ptr(d_frame_counts), _ptr(d_drift), _ptr(stream))
+    if rc != 0:
+        raise GvtmError(rc, lib.gvtm_last_error().decode() or lib.gvtm_status_string(rc).decode())
 
 
 def _ptr(x):

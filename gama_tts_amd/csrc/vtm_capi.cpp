@@ -13,6 +13,7 @@
 #include "../../include/gama_vtm.h"
 #include "vtm_design.hpp"
 #include "vtm_kernels.hpp"
+#include "vtm_tracks.hpp"
 #include "vtm_math.hpp"
 
 namespace {
@@ -320,6 +321,80 @@ int gvtm_debug_device_float_math(gvtm_plan* plan, int kind, const float* x, size
 	(void) hipFree(dout);
 	if (e != hipSuccess) return fail_hip(e, "float math probe");
 	return GVTM_OK;
+}
+
+size_t gvtm_tracks_frame_count(const gvtm_track_config* config, const gvtm_event* events, size_t n_events)
+{
+	if (!config || (!events && n_events > 0)) { fail(GVTM_ERR_INVALID_ARGUMENT, "null config or events"); return static_cast<size_t>(-1); }
+	gvtm::TrackConstants k;
+	const char* why = gvtm::design_tracks(*config, k);
+	if (why[0]) { fail(GVTM_ERR_INVALID_ARGUMENT, why); return static_cast<size_t>(-1); }
+	return gvtm::tracks_frame_count(k.control_period, events, n_events);
+}
+
+int gvtm_generate_tracks_device(int device, const gvtm_track_config* config, const gvtm_event* d_events,
+		const int64_t* d_event_offsets, size_t batch, size_t max_frames, float* d_params, int32_t* d_frame_counts,
+		gvtm_drift_state* d_drift, void* hip_stream)
+{
+	if (!config || !d_event_offsets || (!d_params && max_frames > 0)) return fail(GVTM_ERR_INVALID_ARGUMENT, "null argument");
+	gvtm::TrackArgs args{};
+	const char* why = gvtm::design_tracks(*config, args.k);
+	if (why[0]) return fail(GVTM_ERR_INVALID_ARGUMENT, why);
+	if (batch == 0) return GVTM_OK;
+	if (!d_events) return fail(GVTM_ERR_INVALID_ARGUMENT, "null events");
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(GVTM_ERR_NO_DEVICE, "no HIP device available (track generation has no CPU path)");
+	if (device < 0 || device >= n) return fail(GVTM_ERR_NO_DEVICE, "device index out of range");
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	args.events = d_events;
+	args.event_offsets = d_event_offsets;
+	args.batch = batch;
+	args.max_frames = max_frames;
+	args.params = d_params;
+	args.frame_counts = d_frame_counts;
+	args.drift = d_drift;
+	e = gvtm::launch_tracks(args, static_cast<hipStream_t>(hip_stream));
+	if (e != hipSuccess) return fail_hip(e, "track generation launch");
+	return GVTM_OK;
+}
+
+int gvtm_generate_tracks_host(int device, const gvtm_track_config* config, const gvtm_event* events,
+		const int64_t* event_offsets, size_t batch, size_t max_frames, float* params, int32_t* frame_counts,
+		gvtm_drift_state* drift)
+{
+	if (!config || !event_offsets || (!params && max_frames > 0)) return fail(GVTM_ERR_INVALID_ARGUMENT, "null argument");
+	if (batch == 0) return GVTM_OK;
+	if (!events) return fail(GVTM_ERR_INVALID_ARGUMENT, "null events");
+	for (size_t b = 0; b < batch; ++b) {
+		if (event_offsets[b + 1] < event_offsets[b] || event_offsets[0] != 0) return fail(GVTM_ERR_INVALID_ARGUMENT, "event_offsets must start at 0 and not decrease");
+	}
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(GVTM_ERR_NO_DEVICE, "no HIP device available (track generation has no CPU path)");
+	if (device < 0 || device >= n) return fail(GVTM_ERR_NO_DEVICE, "device index out of range");
+	hipError_t e = hipSetDevice(device);
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	const size_t n_events = static_cast<size_t>(event_offsets[batch]);
+	DeviceBuffer d_ev, d_off, d_par, d_cnt, d_dr;
+	int rc = GVTM_OK;
+	auto done = [&](int code) { d_ev.release(); d_off.release(); d_par.release(); d_cnt.release(); d_dr.release(); return code; };
+	if ((e = d_ev.ensure(sizeof(gvtm_event) * (n_events ? n_events : 1))) != hipSuccess) return done(fail_hip(e, "hipMalloc"));
+	if ((e = d_off.ensure(sizeof(int64_t) * (batch + 1))) != hipSuccess) return done(fail_hip(e, "hipMalloc"));
+	if ((e = d_par.ensure(sizeof(float) * 16 * (batch * max_frames ? batch * max_frames : 1))) != hipSuccess) return done(fail_hip(e, "hipMalloc"));
+	if ((e = d_cnt.ensure(sizeof(int32_t) * batch)) != hipSuccess) return done(fail_hip(e, "hipMalloc"));
+	if (drift && (e = d_dr.ensure(sizeof(gvtm_drift_state) * batch)) != hipSuccess) return done(fail_hip(e, "hipMalloc"));
+	if (n_events && (e = hipMemcpy(d_ev.ptr, events, sizeof(gvtm_event) * n_events, hipMemcpyHostToDevice)) != hipSuccess) return done(fail_hip(e, "H2D events"));
+	if ((e = hipMemcpy(d_off.ptr, event_offsets, sizeof(int64_t) * (batch + 1), hipMemcpyHostToDevice)) != hipSuccess) return done(fail_hip(e, "H2D offsets"));
+	if (drift && (e = hipMemcpy(d_dr.ptr, drift, sizeof(gvtm_drift_state) * batch, hipMemcpyHostToDevice)) != hipSuccess) return done(fail_hip(e, "H2D drift"));
+	if ((e = hipMemset(d_par.ptr, 0, sizeof(float) * 16 * batch * max_frames)) != hipSuccess) return done(fail_hip(e, "hipMemset"));
+	rc = gvtm_generate_tracks_device(device, config, static_cast<const gvtm_event*>(d_ev.ptr), static_cast<const int64_t*>(d_off.ptr), batch,
+			max_frames, static_cast<float*>(d_par.ptr), static_cast<int32_t*>(d_cnt.ptr), drift ? static_cast<gvtm_drift_state*>(d_dr.ptr) : nullptr, nullptr);
+	if (rc != GVTM_OK) return done(rc);
+	if ((e = hipDeviceSynchronize()) != hipSuccess) return done(fail_hip(e, "track generation kernel"));
+	if (params && (e = hipMemcpy(params, d_par.ptr, sizeof(float) * 16 * batch * max_frames, hipMemcpyDeviceToHost)) != hipSuccess) return done(fail_hip(e, "D2H frames"));
+	if (frame_counts && (e = hipMemcpy(frame_counts, d_cnt.ptr, sizeof(int32_t) * batch, hipMemcpyDeviceToHost)) != hipSuccess) return done(fail_hip(e, "D2H counts"));
+	if (drift && (e = hipMemcpy(drift, d_dr.ptr, sizeof(gvtm_drift_state) * batch, hipMemcpyDeviceToHost)) != hipSuccess) return done(fail_hip(e, "D2H drift"));
+	return done(GVTM_OK);
 }
 
 int gvtm_plan_set_timing(gvtm_plan* plan, int enabled)

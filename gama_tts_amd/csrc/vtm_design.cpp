@@ -370,4 +370,54 @@ bool output_count_for_steps(const DeviceConstants& k, uint64_t steps, uint64_t& 
 	return p_star <= fills;
 }
 
+// --- parameter-track generation (vtm_tracks.hip) -----------------------------------------------------
+
+const char* design_tracks(const gvtm_track_config& c, TrackConstants& k)
+{
+	if (c.control_period_ms < 1 || c.control_period_ms > 1000) return "control_period_ms out of range";
+	if (c.reserved_ != 0) return "reserved_ must be 0";
+	k = TrackConstants{};
+	k.control_period = c.control_period_ms;
+	k.macro_intonation = c.macro_intonation != 0;
+	k.micro_intonation = c.micro_intonation != 0;
+	k.intonation_drift = c.intonation_drift != 0;
+	k.smooth_intonation = c.smooth_intonation != 0;
+	k.initial_pitch = c.initial_pitch;
+	k.mean_pitch = c.mean_pitch;
+	if (k.intonation_drift) {
+		// DriftGenerator::setUp (DriftGenerator.cpp:49-56) and Butterworth2LowPassFilter<double>::update
+		// (vtm/Butterworth2LowpassFilter.h:88-107, including its range check)
+		if (!(c.drift_sample_rate > 0.0) || c.drift_lowpass_cutoff < 1.0 || c.drift_lowpass_cutoff > c.drift_sample_rate * 0.48) {
+			return "drift_lowpass_cutoff must lie between 1 Hz and 0.48 of drift_sample_rate";
+		}
+		k.pitch_deviation = c.drift_deviation * 2.0;
+		k.pitch_offset = c.drift_deviation;
+		const double wcT = 2.0 * std::tan(kPi * c.drift_lowpass_cutoff / c.drift_sample_rate);
+		const double wc2T2 = wcT * wcT;
+		const double c1 = 2.0 * std::sqrt(2.0) * wcT;
+		const double c2 = 1.0 / (wc2T2 + c1 + 4.0);
+		k.b0 = c2 * wc2T2;
+		k.b1 = 2.0 * k.b0;
+		k.a1 = c2 * (2.0 * wc2T2 - 8.0);
+		k.a2 = c2 * (wc2T2 - c1 + 4.0);
+	}
+	return "";
+}
+
+size_t tracks_frame_count(int control_period, const gvtm_event* events, size_t n_events)
+{
+	// the control-period loop of EventList::generateOutput (EventList.cpp:985-1032) without the arithmetic
+	if (n_events < 2) return 0;
+	size_t target = 1, n = 0;
+	long long now = 0;
+	while (target < n_events) {
+		++n;
+		now += control_period;
+		if (now >= events[target].time_ms) {
+			if (++target == n_events) break;
+		}
+	}
+	return n;
+}
+
 } // namespace gvtm

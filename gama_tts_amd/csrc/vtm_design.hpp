@@ -81,4 +81,22 @@ double amplitude_60db(double db);
 // defect would trigger (see DESIGN.md "SRC flush overrun").
 bool output_count_for_steps(const DeviceConstants& k, uint64_t steps, uint64_t& n_out);
 
+// --- parameter-track generation (vtm_tracks.hip) ---
+
+// gvtm_track_config with the drift generator's filter designed (DriftGenerator::setUp,
+// Butterworth2LowPassFilter<double>::update) — plain data, passed to the kernel by value
+struct TrackConstants {
+	int control_period;
+	int macro_intonation, micro_intonation, intonation_drift, smooth_intonation;
+	double initial_pitch, mean_pitch;
+	double pitch_deviation, pitch_offset; // deviation * 2, deviation
+	double b0, b1, a1, a2;                // Butterworth2LowPassFilter coefficients
+};
+
+// "" on success, otherwise what is wrong with the configuration
+const char* design_tracks(const gvtm_track_config& cfg, TrackConstants& out);
+
+// frames generateOutput() pushes for one event list (host; the loop over control periods without the arithmetic)
+size_t tracks_frame_count(int control_period, const gvtm_event* events, size_t n_events);
+
 } // namespace gvtm

@@ -179,6 +179,66 @@ int gvtm_normalize_batch_device(gvtm_plan* plan, const float* d_audio, size_t ba
 int gvtm_plan_set_timing(gvtm_plan* plan, int enabled);
 double gvtm_plan_take_kernel_ms(gvtm_plan* plan, int* launches_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Parameter-track generation: the step in front of the vocal-tract path, for a batch.
+ * Replaces EventList::generateOutput() (vtm_control_model/EventList.cpp:930-1091) together with
+ * DriftGenerator::drift() (vtm_control_model/DriftGenerator.cpp:72-84): event lists in, one
+ * float32[16] frame per control period out, laid out as gvtm_synthesize_batch_device() reads them
+ * (the frames never leave the device).  Bit-identical to the reference.
+ */
+
+/* One EventList event (vtm_control_model/EventList.h:117-160), flattened.  A parameter the event does
+ * not set holds Event::EMPTY_PARAMETER = +infinity (HUGE_VAL). */
+typedef struct gvtm_event {
+	int32_t time_ms;     /* Event::time */
+	int32_t has_interp;  /* Event::interpData present */
+	double interp[4];    /* InterpolationData a, b, c, d (macro intonation, EventList.h:105-115) */
+	double param[16];    /* Event::parameters */
+	double special[16];  /* Event::specialParameters */
+} gvtm_event;
+
+typedef struct gvtm_track_config {
+	int32_t control_period_ms;   /* EventList::controlPeriod_ (1..4), = 1000 / control rate */
+	int32_t macro_intonation;    /* EventList flags (EventList.h:182-192) */
+	int32_t micro_intonation;
+	int32_t intonation_drift;
+	int32_t smooth_intonation;
+	int32_t reserved_;           /* must be 0 */
+	double initial_pitch;        /* EventList::initialPitch_ (Controller.cpp:70) */
+	double mean_pitch;           /* EventList::meanPitch_ = pitch_offset + reference_glottal_pitch (Controller.cpp:71) */
+	double drift_deviation;      /* DriftGenerator::setUp(deviation, sampleRate, lowpassCutoff), Controller.cpp:73 */
+	double drift_sample_rate;
+	double drift_lowpass_cutoff;
+} gvtm_track_config;
+
+/* DriftGenerator state (noise seed, Butterworth filter memory).  The reference keeps one generator per
+ * Controller, running on from chunk to chunk; a fresh one is {0.7892347, 0, 0, 0, 0}. */
+typedef struct gvtm_drift_state {
+	double seed, x1, x2, y1, y2;
+} gvtm_drift_state;
+
+/* Frames generateOutput() pushes for one event list (host-side, no device needed); (size_t)-1 on a
+ * bad configuration. */
+size_t gvtm_tracks_frame_count(const gvtm_track_config* config, const gvtm_event* events, size_t n_events);
+
+/*
+ * Batch generation, everything resident in device memory.
+ *   d_events        all utterances' events back to back
+ *   d_event_offsets [batch + 1] int64: utterance b owns events [offsets[b], offsets[b+1])
+ *   d_params        [batch][max_frames][16] float32 out; frames beyond max_frames are dropped
+ *   d_frame_counts  [batch] int32 out: frames generateOutput() produces (may exceed max_frames), may be NULL
+ *   d_drift         [batch] in/out drift-generator states, or NULL: a fresh generator per utterance
+ * d_params / d_frame_counts are exactly what gvtm_synthesize_batch_device() takes.
+ */
+int gvtm_generate_tracks_device(int device, const gvtm_track_config* config, const gvtm_event* d_events,
+		const int64_t* d_event_offsets, size_t batch, size_t max_frames, float* d_params, int32_t* d_frame_counts,
+		gvtm_drift_state* d_drift, void* hip_stream);
+
+/* Same with host buffers (H2D, kernel, D2H, synchronous). */
+int gvtm_generate_tracks_host(int device, const gvtm_track_config* config, const gvtm_event* events,
+		const int64_t* event_offsets, size_t batch, size_t max_frames, float* params, int32_t* frame_counts,
+		gvtm_drift_state* drift);
+
 #ifdef __cplusplus
 }
 #endif
