@@ -93,7 +93,7 @@ struct V2Shape {
 #ifdef GVTM_TUNE_C1
 	static constexpr int C = (U_ == 1) ? GVTM_TUNE_C1 : (U_ == 2 ? GVTM_TUNE_C2 : GVTM_TUNE_C4);
 #else
-	static constexpr int C = (U_ == 1) ? 60 : (U_ == 2 ? (kAllFloat ? 96 : (kMixed ? 48 : 36)) : (kAllFloat ? 48 : 24));
+	static constexpr int C = (U_ == 1) ? 60 : (U_ == 2 ? (kAllFloat ? 96 : (kMixed ? 48 : 36)) : (U_ == 8 ? 24 : (kAllFloat ? 48 : 24)));
 #endif
 #ifndef GVTM_TUNE_NH_MULTI
 #define GVTM_TUNE_NH_MULTI 7
@@ -101,7 +101,12 @@ struct V2Shape {
 #ifndef GVTM_TUNE_NH_SINGLE
 #define GVTM_TUNE_NH_SINGLE 3
 #endif
-	static constexpr int NH = (U_ == 1) ? GVTM_TUNE_NH_SINGLE : GVTM_TUNE_NH_MULTI; // 8 resp. 12 wavefronts per workgroup
+#ifndef GVTM_TUNE_NH_OCTO
+#define GVTM_TUNE_NH_OCTO 6
+#endif
+	// 8 resp. 12 wavefronts per workgroup; eight rows: two wavefronts per serial role + 6 helpers = 16
+	static constexpr int NH = (U_ == 1) ? GVTM_TUNE_NH_SINGLE : (U_ == 8 ? GVTM_TUNE_NH_OCTO : GVTM_TUNE_NH_MULTI);
+	static constexpr int kWaves = 5 * ((U_ + 3) / 4) + NH;
 	// internal-rate ring: two chunks + resampler history + flush zeros, a power of two
 	static constexpr int XR = (2 * C + 4 * kMaxPad <= 512) ? 512 : 1024;
 };
@@ -116,7 +121,7 @@ static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t str
 			static_cast<int>(lds));
 	if (e != hipSuccess) return e;
 	const unsigned groups = static_cast<unsigned>((batch + S::U - 1) / S::U);
-	hipLaunchKernelGGL(fn, dim3(groups), dim3((5 + S::NH) * 64), lds, stream, args);
+	hipLaunchKernelGGL(fn, dim3(groups), dim3(S::kWaves * 64), lds, stream, args);
 	return hipGetLastError();
 }
 
@@ -131,9 +136,10 @@ int synth_rows(int precision, size_t batch, int requested)
 	// utterances per workgroup = DPP rows used by the serial wavefronts.  One row keeps the most
 	// workgroups in flight (best latency for small batches); more rows amortise the serial
 	// instruction streams once there are more utterances than compute units.
-	const int max_rows = precision == GVTM_PRECISION_F64 ? 2 : 4; // fp64 resampler tables leave LDS for two rows only
+	// fp64 resampler tables leave LDS for two rows only; eight rows (two wavefronts per serial role) fit in float
+	const int max_rows = precision == GVTM_PRECISION_F64 ? 2 : (precision == GVTM_PRECISION_F32 ? 8 : 4);
 	int rows = requested;
-	if (rows != 1 && rows != 2 && rows != 4) {
+	if (rows != 1 && rows != 2 && rows != 4 && rows != 8) {
 		rows = batch > 512 ? 4 : (batch > 256 ? 2 : 1);
 	}
 	return rows > max_rows ? max_rows : rows;
@@ -149,6 +155,9 @@ static size_t v2_lds()
 template <typename CT, typename ST>
 static size_t v2_lds_rows(int rows)
 {
+	if constexpr (sizeof(CT) == 4) {
+		if (rows == 8) return v2_lds<CT, ST, 8>();
+	}
 	return rows == 4 ? v2_lds<CT, ST, 4>() : (rows == 2 ? v2_lds<CT, ST, 2>() : v2_lds<CT, ST, 1>());
 }
 
@@ -180,6 +189,9 @@ static hipError_t launch_v2_d(const SynthArgs& args, size_t batch, hipStream_t s
 template <typename CT, typename ST>
 static hipError_t launch_v2_rows(const SynthArgs& args, size_t batch, int rows, hipStream_t stream)
 {
+	if constexpr (sizeof(CT) == 4) {
+		if (rows == 8) return launch_v2_d<CT, ST, 8>(args, batch, stream);
+	}
 	if (rows == 4) return launch_v2_d<CT, ST, 4>(args, batch, stream);
 	if (rows == 2) return launch_v2_d<CT, ST, 2>(args, batch, stream);
 	return launch_v2_d<CT, ST, 1>(args, batch, stream);
