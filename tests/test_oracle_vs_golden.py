@@ -19,6 +19,8 @@ KAT = {
     "ramp_m0": (88108, 3.076802642e+00, 1.228036941e-03),
     "const_m3": (88077, 1.073991490e+01, 1.668861834e-03),
     "ramp_m3": (88077, 4.196292139e+00, 2.267686650e-03),
+    "const_m1": (88108, 7.871396222e+00, 7.547301939e-04),  # model 1 = VocalTractModel0<float>
+    "ramp_m1": (88108, 3.077012386e+00, 1.231163274e-03),
     "const_m4": (88077, 1.073981937e+01, 1.675571664e-03),
     "ramp_m4": (88077, 4.196179109e+00, 2.232487779e-03),
 }
