@@ -58,9 +58,10 @@ typedef enum gvtm_precision {
 	GVTM_PRECISION_F64 = 0,  /* everything in fp64, like VocalTractModel0<double> */
 	GVTM_PRECISION_MIXED = 1, /* fp64 sources, tube and filters; fp32 sample-rate converter (tables, window, MACs) */
 	GVTM_PRECISION_F32 = 2    /* everything in fp32, like VocalTractModel0<float> (reference model 1) and
-	                             VocalTractModel2<float,D>: design tables and constants computed in float too.
-	                             Parity target is the reference's FLOAT model, which itself differs from its
-	                             double model by several percent of peak after a few seconds (oscillator phase) */
+	                             VocalTractModel2<float,D>: design tables and constants computed in float too, every
+	                             rounding reproduced — the output is bit-identical to the reference's FLOAT model
+	                             (which itself differs from its double model by several percent of peak after a
+	                             few seconds: oscillator phase, 47 instead of 49 FIR taps) */
 } gvtm_precision;
 
 /* Tube topology. */
