@@ -5,7 +5,8 @@
 
 One "step" = one pass of the hot path (parameter frames in HBM -> audio samples in HBM) over
 one batch of synthetic utterances.  N=1 runs BASELINE.json configs[1] (batch 256, 500 frames
-= 2 s, VocalTractModel0 semantics, 44.1 kHz out).  For N>1 the driver starts one process per
+= 2 s, "VTM0 fp32" = VocalTractModel0<float> semantics, 44.1 kHz out; the device output is
+bit-identical to that reference class); the fp64 model and batch 4096 ride along under "extras".  For N>1 the driver starts one process per
 GPU (torch.distributed.run); every rank synthesizes its own batch (weak scaling, independent
 utterances, no data-path collective — SURVEY.md 8e); the only communication is the barrier
 and the MAX of the elapsed time.
@@ -89,8 +90,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=500, help="control frames per utterance (4 ms each)")
     ap.add_argument("--delay", type=int, default=1, help="SectionDelay (1 = VocalTractModel0)")
-    ap.add_argument("--precision", choices=["f64", "mixed", "f32"], default="f64",
-                    help="f64 = VocalTractModel0<double> semantics (default); f32 = VocalTractModel0<float> (reference model 1); "
+    ap.add_argument("--precision", choices=["f64", "mixed", "f32"], default="f32",
+                    help="f32 (default; BASELINE configs[1] is 'VTM0 fp32') = VocalTractModel0<float>, reference model 1, "
+                         "output bit-identical to it; f64 = VocalTractModel0<double>, model 0 (reported under 'extras'); "
                          "mixed = fp64 with an fp32 resampler")
     ap.add_argument("--output-rate", type=float, default=44100.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -7,7 +7,7 @@ tag=${1:-r01}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py --steps 20 --warmup 3 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-python3 bench.py --steps 20 --warmup 3 --precision f32 > $out/${tag}_bench_f32.json 2>> $out/${tag}_bench.err
+python3 bench.py --steps 20 --warmup 3 --precision f64 > $out/${tag}_bench_f64.json 2>> $out/${tag}_bench.err
 for p in f64 f32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats_$p -- python3 bench.py --steps 5 --warmup 2 --precision $p --no-cpu-baseline --no-extras > $out/${tag}_stats_$p.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch_$p -- python3 bench.py --steps 3 --warmup 1 --precision $p --no-cpu-baseline --no-extras > $out/${tag}_fetch_$p.log 2>&1
