@@ -30,8 +30,8 @@ def test_plugin_through_reference_loader(name, golden, tmp_path):
     ref = golden[name + "__out"]
     assert out.size == ref.size == int(info["N"])
     assert float(info["fs"]) == 20034.0
-    err = np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max()
-    assert err <= 1e-9, err
+    from test_gpu_parity import _within, _peak_err
+    assert _within(out, ref, 1e-9), _peak_err(out, ref)
 
 
 @pytest.mark.skipif(oracle.ref_binary() is None, reason="oracle/_ref/ref_vtm (the compiled reference) not present")
@@ -66,7 +66,8 @@ def test_plugin_thirty_section_tube_through_reference_loader(golden, tmp_path):
     out, info = oracle.ref_synthesize(tr, "2000:" + PLUGIN, config=cfg, tmpdir=str(tmp_path))
     ref = golden["rand5_m4__out"]
     assert out.size == ref.size and float(info["fs"]) == 60102.0
-    assert np.abs(out.astype(np.float64) - ref).max() / np.abs(ref).max() <= 1e-9
+    from test_gpu_parity import _within, _peak_err
+    assert _within(out, ref, 1e-9), _peak_err(out, ref)
 
 
 def _make_voice_dir(root, model="0"):

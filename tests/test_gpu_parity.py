@@ -2,7 +2,11 @@
 
 Tolerance: the metric is max|gpu - ref| / max|ref| per utterance (SURVEY.md hard part 6;
 a per-sample relative error is meaningless at zero crossings).
-  * fp64 path: 1e-9  (the reference itself only reproduces to 1.6e-8 across compilers, E9)
+  * fp64 path: 1e-9  (the reference itself only reproduces to 1.6e-8 across compilers, E9).  Both sides
+    are float32 samples, so a double-level difference of 1e-13 can still flip the rounding of a sample:
+    a sample may therefore also differ by one float32 ulp of itself (6e-8 of the sample; on batch 256 of
+    configs[2], 251 utterances are bit-identical and the rest carry a handful of such flips,
+    profiles/r01d_config3_parity.json).
   * mixed path: 1e-5 (BASELINE.json north_star)
 Sample counts are exact in both.
 """
@@ -27,6 +31,15 @@ def _plan(case_overrides=None, rate=44100.0, delay=1, crate=250.0, precision=cap
     return g.Plan(g.config_from_dict(d, rate, delay, precision, layout), crate, 0)
 
 
+def _within(got, ref, tol, peak=None):
+    """Every sample within max(tol * peak, one float32 ulp of the reference sample)."""
+    ref64 = ref.astype(np.float64)
+    peak = float(np.abs(ref64).max()) if peak is None else float(peak)
+    d = np.abs(got.astype(np.float64) - ref64)
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    return bool((d <= np.maximum(ulp, tol * max(peak, 1e-300))).all())
+
+
 def _peak_err(got, ref):
     ref = ref.astype(np.float64)
     peak = np.abs(ref).max()
@@ -47,16 +60,15 @@ def test_reference_vectors(case, precision, tol, golden):
     audio, counts, maxabs = plan.synthesize_host(tr[None])
     assert counts[0] == m["n"]
     out = audio[0]
+    scale = m["maxabs"] if m["maxabs"] > 0 else 1.0
     if case["store"] == "full":
         ref = golden[case["name"] + "__out"]
-        err = _peak_err(out, ref)
+        assert _within(out, ref, tol, scale), _peak_err(out, ref)
     else:
         ref = golden[case["name"] + "__strided"]
-        scale = m["maxabs"] if m["maxabs"] > 0 else 1.0
-        err = float(np.abs(out[:: golden_cases.DIGEST_STRIDE].astype(np.float64) - ref).max() / scale)
-        assert abs(float(out.astype(np.float64).sum()) - m["sum"]) <= 50 * tol * scale * m["n"] ** 0.5 + 1e-12
-    assert err <= tol, err
-    assert maxabs[0] == pytest.approx(m["maxabs"], rel=10 * tol, abs=1e-12)
+        assert _within(out[:: golden_cases.DIGEST_STRIDE], ref, tol, scale)
+        assert abs(float(out.astype(np.float64).sum()) - m["sum"]) <= 50 * max(tol, 1e-8) * scale * m["n"] ** 0.5 + 1e-12
+    assert maxabs[0] == pytest.approx(m["maxabs"], rel=max(10 * tol, 2e-7), abs=1e-12)
 
 
 @pytest.mark.parametrize("delay", [1, 2, 3])
@@ -67,7 +79,7 @@ def test_random_batch_against_oracle(delay):
     ref = oracle.synthesize_batch(oracle.male_config(44100.0, delay), params)
     assert audio.shape == ref.shape and (counts == ref.shape[1]).all()
     for b in range(params.shape[0]):
-        assert _peak_err(audio[b], ref[b]) <= TOL_F64
+        assert _within(audio[b], ref[b], TOL_F64), _peak_err(audio[b], ref[b])
 
 
 def test_ragged_and_empty_utterances():
@@ -79,7 +91,7 @@ def test_ragged_and_empty_utterances():
     for b, f in enumerate(frames):
         ref = oracle.synthesize(cfg, params[b, :f]) if f else np.zeros(oracle.output_count(cfg, 0), np.float32)
         assert counts[b] == ref.size == plan.output_count(int(f))
-        assert _peak_err(audio[b, : ref.size], ref) <= TOL_F64
+        assert _within(audio[b, : ref.size], ref, TOL_F64), _peak_err(audio[b, : ref.size], ref)
     assert maxabs[0] == 0.0
 
 
@@ -134,7 +146,7 @@ def test_full_size_properties_config2():
     assert np.array_equal(head[:, :safe], audio[:8, :safe])
     cfg = oracle.male_config()
     for b in (0, 101, 255):
-        assert _peak_err(audio[b], oracle.synthesize(cfg, params[b])) <= TOL_F64
+        assert _within(audio[b], oracle.synthesize(cfg, params[b]), TOL_F64), _peak_err(audio[b], oracle.synthesize(cfg, params[b]))
 
 
 @pytest.mark.parametrize("rows,precision,tol", [(2, capi.PRECISION_F64, TOL_F64), (2, capi.PRECISION_MIXED, TOL_MIXED),
@@ -152,7 +164,7 @@ def test_multi_row_workgroups(rows, precision, tol, delay, monkeypatch):
     for b, f in enumerate(frames):
         ref = oracle.synthesize(cfg, params[b, :f]) if f else np.zeros(oracle.output_count(cfg, 0), np.float32)
         assert counts[b] == ref.size
-        assert _peak_err(audio[b, : ref.size], ref) <= tol, (b, f)
+        assert _within(audio[b, : ref.size], ref, tol), _peak_err(audio[b, : ref.size], ref)
         assert maxabs[b] == np.abs(audio[b, : ref.size]).max()
 
 
@@ -169,7 +181,7 @@ def test_one_step_per_frame_and_chunk_aligned_lengths(frames):
     for b in range(2):
         ref = oracle.synthesize(cfg, params[b], control_rate=20034.0)
         assert counts[b] == ref.size
-        assert _peak_err(audio[b, : ref.size], ref) <= TOL_F64
+        assert _within(audio[b, : ref.size], ref, TOL_F64), _peak_err(audio[b, : ref.size], ref)
 
 
 # Over 1.2 M internal steps the last-bit differences between the device's and glibc's exp2/pow
@@ -194,7 +206,7 @@ def test_long_form_oversampled_tube(precision, tol):
     for b in range(2):
         ref = oracle.synthesize(cfg, pool[b])
         assert ref.size == n
-        assert _peak_err(audio[b], ref) <= tol
+        assert _within(audio[b], ref, tol), _peak_err(audio[b], ref)
         assert np.array_equal(audio[b], audio[b + 2]) and np.array_equal(audio[b], audio[b + 4])
 
 
@@ -210,4 +222,4 @@ def test_thirty_section_tube_batch_against_oracle():
     for b, f in enumerate(frames):
         ref = oracle.synthesize(cfg, params[b, :f]) if f else np.zeros(oracle.output_count(cfg, 0), np.float32)
         assert counts[b] == ref.size
-        assert _peak_err(audio[b, : ref.size], ref) <= TOL_F64
+        assert _within(audio[b, : ref.size], ref, TOL_F64), _peak_err(audio[b, : ref.size], ref)

@@ -83,5 +83,5 @@ def test_events_to_audio_on_the_device(golden_tracks):
         assert d_counts[b].item() == frames.shape[0]
         ref = oracle.synthesize(cfg, frames)
         assert d_n[b].item() == ref.size
-        err = np.abs(audio[b, : ref.size].astype(np.float64) - ref).max() / np.abs(ref).max()
-        assert err <= 1e-9, (b, err)
+        from test_gpu_parity import _within, _peak_err
+        assert _within(audio[b, : ref.size], ref, 1e-9), (b, _peak_err(audio[b, : ref.size], ref))
