@@ -1,5 +1,7 @@
 #include "batch_controller.hpp"
 
+#include <thread>
+
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -83,15 +85,25 @@ gvtm_config config_from_keys(const std::map<std::string, std::string>& k, int pr
 	return c;
 }
 
-void BatchController::init(const std::map<std::string, std::string>& keys, unsigned control_period_ms, int device, int precision)
+void BatchController::init(const std::map<std::string, std::string>& keys, unsigned control_period_ms, const std::vector<int>& devices, int precision)
 {
 	if (control_period_ms == 0 || control_period_ms > 4) throw std::runtime_error("Invalid control period."); // VTMControlModelConfiguration.cpp:38
+	if (devices.empty()) throw std::runtime_error("no device given");
 	config_ = config_from_keys(keys, precision);
 	const double control_rate = 1000.0 / control_period_ms;
-	if (gvtm_plan_create(&config_, control_rate, device, &plan_) != GVTM_OK) throw std::runtime_error(gvtm_last_error());
+	for (int device : devices) {
+		gvtm_plan* plan = nullptr;
+		if (gvtm_plan_create(&config_, control_rate, device, &plan) != GVTM_OK) {
+			const std::string why = gvtm_last_error();
+			for (gvtm_plan* p : plans_) gvtm_plan_destroy(p);
+			plans_.clear();
+			throw std::runtime_error(why);
+		}
+		plans_.push_back(plan);
+	}
 }
 
-BatchController::BatchController(const std::string& voice_dir, int device, int precision)
+void BatchController::loadVoice(const std::string& voice_dir, const std::vector<int>& devices, int precision)
 {
 	const std::string dir = (!voice_dir.empty() && voice_dir.back() == '/') ? voice_dir : voice_dir + '/';
 	const auto index = read_key_value_file(dir + "_index.txt");
@@ -105,23 +117,33 @@ BatchController::BatchController(const std::string& voice_dir, int device, int p
 	auto vn = control.find("variant_name");
 	if (vn == control.end()) throw std::runtime_error("Key 'variant_name' not found.");
 	for (const auto& kv : read_key_value_file(entry("variant_dir") + vn->second + ".txt")) keys[kv.first] = kv.second; // insert(): overwrite
-	init(keys, static_cast<unsigned>(num(control, "control_period")), device, precision);
+	init(keys, static_cast<unsigned>(num(control, "control_period")), devices, precision);
+}
+
+BatchController::BatchController(const std::string& voice_dir, int device, int precision)
+{
+	loadVoice(voice_dir, std::vector<int>{device}, precision);
+}
+
+BatchController::BatchController(const std::string& voice_dir, const std::vector<int>& devices, int precision)
+{
+	loadVoice(voice_dir, devices, precision);
 }
 
 BatchController::BatchController(const std::map<std::string, std::string>& merged_keys, unsigned control_period_ms, int device, int precision)
 {
-	init(merged_keys, control_period_ms, device, precision);
+	init(merged_keys, control_period_ms, std::vector<int>{device}, precision);
 }
 
 BatchController::~BatchController()
 {
-	gvtm_plan_destroy(plan_);
+	for (gvtm_plan* p : plans_) gvtm_plan_destroy(p);
 }
 
 double BatchController::internalSampleRate() const
 {
 	gvtm_info info{};
-	gvtm_plan_info(plan_, &info);
+	gvtm_plan_info(plans_.front(), &info);
 	return info.internal_sample_rate;
 }
 
@@ -153,6 +175,7 @@ std::size_t BatchController::addUtterance(std::vector<float> frames)
 void BatchController::synthesize()
 {
 	const std::size_t batch = utterances_.size();
+	shards_.assign(plans_.size(), {0, 0});
 	if (batch == 0) return;
 	std::size_t max_frames = 0;
 	std::vector<int32_t> frames(batch);
@@ -164,14 +187,35 @@ void BatchController::synthesize()
 	for (std::size_t b = 0; b < batch; ++b) {
 		std::copy(utterances_[b].begin(), utterances_[b].end(), params.begin() + static_cast<std::ptrdiff_t>(b * max_frames * GVTM_N_PARAM));
 	}
-	stride_ = gvtm_output_count(plan_, max_frames);
+	stride_ = gvtm_output_count(plans_.front(), max_frames);
 	if (stride_ == static_cast<std::size_t>(-1)) throw std::runtime_error(gvtm_last_error());
 	audio_.assign(batch * stride_, 0.0f);
 	counts_.assign(batch, 0);
 	maxabs_.assign(batch, 0.0f);
-	const int rc = gvtm_synthesize_batch_host(plan_, params.data(), frames.data(), batch, max_frames, audio_.data(), stride_,
-			counts_.data(), maxabs_.data());
-	if (rc != GVTM_OK) throw std::runtime_error(std::string("synthesis failed: ") + gvtm_last_error());
+	// contiguous shards whose sizes differ by at most one; every shard on its own host thread and device
+	const std::size_t n_dev = plans_.size();
+	const std::size_t base = batch / n_dev, extra = batch % n_dev;
+	std::vector<std::string> errors(n_dev);
+	std::vector<std::thread> workers;
+	std::size_t lo = 0;
+	for (std::size_t d = 0; d < n_dev; ++d) {
+		const std::size_t hi = lo + base + (d < extra ? 1 : 0);
+		shards_[d] = {lo, hi};
+		if (hi > lo) {
+			auto run = [this, d, lo, hi, max_frames, &params, &frames, &errors]() {
+				const int rc = gvtm_synthesize_batch_host(plans_[d], params.data() + lo * max_frames * GVTM_N_PARAM, frames.data() + lo,
+						hi - lo, max_frames, audio_.data() + lo * stride_, stride_, counts_.data() + lo, maxabs_.data() + lo);
+				if (rc != GVTM_OK) errors[d] = gvtm_last_error(); // thread-local message
+			};
+			if (n_dev == 1) run();
+			else workers.emplace_back(run);
+		}
+		lo = hi;
+	}
+	for (auto& w : workers) w.join();
+	for (const auto& e : errors) {
+		if (!e.empty()) throw std::runtime_error("synthesis failed: " + e);
+	}
 }
 
 const float* BatchController::samples(std::size_t i) const { return audio_.data() + i * stride_; }

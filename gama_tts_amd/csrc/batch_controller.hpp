@@ -9,6 +9,7 @@
 #include <iosfwd>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gama_vtm.h"
@@ -32,6 +33,10 @@ public:
 	// From an already merged configuration and an explicit control period in ms (1..4).
 	BatchController(const std::map<std::string, std::string>& merged_keys, unsigned control_period_ms, int device,
 			int precision = GVTM_PRECISION_F64);
+	// Several devices of one node (BASELINE configs[4]): the queued utterances are cut into contiguous shards,
+	// one per listed device, each synthesized by its own host thread through its own plan and stream; no
+	// exchange between devices (utterances are independent).  A device may be listed twice.
+	BatchController(const std::string& voice_dir, const std::vector<int>& devices, int precision = GVTM_PRECISION_F64);
 	~BatchController();
 	BatchController(const BatchController&) = delete;
 	BatchController& operator=(const BatchController&) = delete;
@@ -42,8 +47,11 @@ public:
 	std::size_t addUtterance(std::vector<float> frames /* [n][16] */);
 	std::size_t size() const { return utterances_.size(); }
 
-	// Controller::synthesize + finishSynthesis for every queued utterance (one device launch).
+	// Controller::synthesize + finishSynthesis for every queued utterance (one launch per device).
 	void synthesize();
+	std::size_t deviceCount() const { return plans_.size(); }
+	// [first, last) utterance indices handed to device slot `d` by the last synthesize()
+	std::pair<std::size_t, std::size_t> shard(std::size_t d) const { return shards_.at(d); }
 
 	double outputSampleRate() const { return config_.output_rate; }
 	double internalSampleRate() const;
@@ -57,9 +65,11 @@ public:
 	// Controller::writeOutputToFile (Controller.cpp:315-328): 16-bit mono RIFF/WAVE.
 	void writeWav(std::size_t i, const std::string& path) const;
 private:
-	void init(const std::map<std::string, std::string>& keys, unsigned control_period_ms, int device, int precision);
+	void init(const std::map<std::string, std::string>& keys, unsigned control_period_ms, const std::vector<int>& devices, int precision);
+	void loadVoice(const std::string& voice_dir, const std::vector<int>& devices, int precision);
 	gvtm_config config_{};
-	gvtm_plan* plan_ = nullptr;
+	std::vector<gvtm_plan*> plans_; // one per device slot
+	std::vector<std::pair<std::size_t, std::size_t>> shards_;
 	std::vector<std::vector<float>> utterances_;
 	std::vector<float> audio_;
 	std::vector<int64_t> counts_;

@@ -128,3 +128,28 @@ def test_batched_vtm_cli_writes_reference_wavs(model, layout, golden, tmp_path):
         assert np.abs(pcm.astype(np.int32) - want).max() <= 1
         assert np.mean(pcm.astype(np.int32) == want) > 0.999
     assert np.abs(_read_wav(os.path.join(out_dir, "hello.wav"))[1]).max() == 31129  # round(0.95 * 32767)
+
+
+def test_batched_cli_shards_across_device_slots(golden, tmp_path):
+    """`-d 0,0,0`: three device slots (the same GPU three times on a one-GPU box), seven utterances -> contiguous
+    shards of 3, 2, 2, each on its own host thread and plan (BASELINE configs[4] layout, no exchange between
+    devices).  Every WAV must equal the one-device result byte for byte."""
+    voice = str(tmp_path / "voice")
+    _make_voice_dir(voice, "0")
+    hello = np.asarray(golden["hello_params"])
+    files = []
+    for n, frames in enumerate([332, 40, 7, 120, 1, 250, 60]):
+        p = str(tmp_path / ("u%d.txt" % n))
+        with open(p, "w") as f:
+            for row in hello[:frames]:
+                f.write(" ".join("%.9g" % v for v in row) + "\n")
+        files.append(p)
+    outs = {}
+    for tag, dev in (("one", "0"), ("three", "0,0,0")):
+        out_dir = str(tmp_path / tag)
+        os.makedirs(out_dir)
+        r = subprocess.run([CLI, "-d", dev, voice, out_dir] + files, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = [open(os.path.join(out_dir, "u%d.wav" % n), "rb").read() for n in range(len(files))]
+    assert outs["one"] == outs["three"]
+    assert len(outs["one"][0]) > 44 and len(outs["one"][4]) > 44
