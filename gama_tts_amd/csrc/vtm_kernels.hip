@@ -87,13 +87,13 @@ struct V2Shape {
 	//          passes), so the longest chunk LDS allows wins: measured on batch 4096 in float, C = 24 / 36 / 48
 	//          -> 24.8 / 21.6 / 18.4 ms; batch 512, C = 24 / 48 / 96 -> 4.71 / 4.64 / 4.38 ms.
 	// LDS per workgroup (KB): float 1x60 65, 2x96 143, 4x48 144; mixed 1x60 94, 2x48 131, 4x24 138;
-	// fp64 1x60 122, 2x36 139.
+	// fp64 1x60 122, 2x48 135 and 4x24 146 (resampler table without its delta half).
 	static constexpr bool kAllFloat = sizeof(CT) == 4;
 	static constexpr bool kMixed = sizeof(CT) == 8 && sizeof(ST) == 4;
 #ifdef GVTM_TUNE_C1
 	static constexpr int C = (U_ == 1) ? GVTM_TUNE_C1 : (U_ == 2 ? GVTM_TUNE_C2 : GVTM_TUNE_C4);
 #else
-	static constexpr int C = (U_ == 1) ? 60 : (U_ == 2 ? (kAllFloat ? 96 : (kMixed ? 48 : 36)) : (U_ == 8 ? 24 : (kAllFloat ? 48 : 24)));
+	static constexpr int C = (U_ == 1) ? 60 : (U_ == 2 ? (kAllFloat ? 96 : 48) : (U_ == 8 ? 24 : (kAllFloat ? 48 : 24)));
 #endif
 #ifndef GVTM_TUNE_NH_MULTI
 #define GVTM_TUNE_NH_MULTI 7
@@ -136,11 +136,14 @@ int synth_rows(int precision, size_t batch, int requested)
 	// utterances per workgroup = DPP rows used by the serial wavefronts.  One row keeps the most
 	// workgroups in flight (best latency for small batches); more rows amortise the serial
 	// instruction streams once there are more utterances than compute units.
-	// fp64 resampler tables leave LDS for two rows only; eight rows (two wavefronts per serial role) fit in float
-	const int max_rows = precision == GVTM_PRECISION_F64 ? 2 : (precision == GVTM_PRECISION_F32 ? 8 : 4);
+	// eight rows (two wavefronts per serial role) fit in float only
+	const int max_rows = precision == GVTM_PRECISION_F32 ? 8 : 4;
 	int rows = requested;
 	if (rows != 1 && rows != 2 && rows != 4 && rows != 8) {
 		rows = batch > 512 ? 4 : (batch > 256 ? 2 : 1);
+		// fp64: four rows fit since the resampler table lost its delta half, but measured no faster than two
+		// (9.2 vs 8.9 ms on batch 1024: the fp64 serial chains spill at 12 wavefronts per workgroup)
+		if (precision == GVTM_PRECISION_F64 && rows > 2) rows = 2;
 	}
 	return rows > max_rows ? max_rows : rows;
 }
@@ -166,7 +169,7 @@ size_t synth_lds_bytes(int precision, int generation, int rows)
 	if (generation == 1) return v1::synth_lds_bytes(precision == GVTM_PRECISION_MIXED);
 	if (precision == GVTM_PRECISION_F32) return v2_lds_rows<float, float>(rows);
 	if (precision == GVTM_PRECISION_MIXED) return v2_lds_rows<double, float>(rows);
-	return rows == 2 ? v2_lds<double, double, 2>() : v2_lds<double, double, 1>();
+	return v2_lds_rows<double, double>(rows);
 }
 
 template <typename CT, typename ST, int U>
@@ -223,8 +226,7 @@ hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int 
 	}
 	if (precision == GVTM_PRECISION_F32) return launch_v2_rows<float, float>(args, batch, rows, stream);
 	if (mixed) return launch_v2_rows<double, float>(args, batch, rows, stream);
-	if (rows == 2) return launch_v2_d<double, double, 2>(args, batch, stream);
-	return launch_v2_d<double, double, 1>(args, batch, stream);
+	return launch_v2_rows<double, double>(args, batch, rows, stream);
 }
 
 // Test hook: the all-float path's per-step conversions evaluated ON THE DEVICE

@@ -149,8 +149,8 @@ def test_full_size_properties_config2():
         assert _within(audio[b], oracle.synthesize(cfg, params[b]), TOL_F64), _peak_err(audio[b], oracle.synthesize(cfg, params[b]))
 
 
-@pytest.mark.parametrize("rows,precision,tol", [(2, capi.PRECISION_F64, TOL_F64), (2, capi.PRECISION_MIXED, TOL_MIXED),
-                                                  (4, capi.PRECISION_MIXED, TOL_MIXED)])
+@pytest.mark.parametrize("rows,precision,tol", [(2, capi.PRECISION_F64, TOL_F64), (4, capi.PRECISION_F64, TOL_F64),
+                                                  (2, capi.PRECISION_MIXED, TOL_MIXED), (4, capi.PRECISION_MIXED, TOL_MIXED)])
 @pytest.mark.parametrize("delay", [1, 3])
 def test_multi_row_workgroups(rows, precision, tol, delay, monkeypatch):
     """Several utterances per workgroup (one DPP row each in the serial wavefronts), ragged
