@@ -18,7 +18,8 @@
 //   <model>: 0,1,2,3,4,5,2000 = VocalTractModel::getInstance factory
 //            (gama_tts/src/vtm/VocalTractModel.cpp:35-59);
 //            "2:D" = VocalTractModel2<double,D> instantiated directly, D in 1..4
-//            "2f:D" = VocalTractModel2<float,D> (no factory number), "4f" = VocalTractModel4<float,1>
+//            "2f:D" = VocalTractModel2<float,D> (no factory number), "4f" = VocalTractModel4<float,1>,
+//            "5f" = VocalTractModel5<float,1>
 //            "2000:<path>" = plugin factory with dll_path=<path>
 //   [repeat] > 1: timing mode, the utterance is synthesised <repeat> times
 //            (reset() between runs, as Controller does, Controller.cpp:231).
@@ -37,6 +38,7 @@
 #include "VocalTractModel.h"
 #include "VocalTractModel2.h"
 #include "VocalTractModel4.h"
+#include "VocalTractModel5.h"
 
 using GS::ConfigurationData;
 using GS::VTM::VocalTractModel;
@@ -75,6 +77,11 @@ static std::unique_ptr<VocalTractModel> make_model(ConfigurationData& cfg, const
 		cfg.put("model", "4");
 		cfg.put("log_parameters", "false");
 		return std::make_unique<GS::VTM::VocalTractModel4<float, 1>>(cfg, false);
+	}
+	if (model == "5f") {
+		cfg.put("model", "5");
+		cfg.put("log_parameters", "false");
+		return std::make_unique<GS::VTM::VocalTractModel5<float, 1>>(cfg, false);
 	}
 	if (model.rfind("2000:", 0) == 0) {
 		cfg.put("model", "2000");

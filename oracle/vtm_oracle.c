@@ -66,6 +66,16 @@ static size_t run(const vtmo_config* cfg, double control_rate, const float* para
 	                        : vtmo_run_f64(cfg, control_rate, params, n_frames, out, cap, internal_signal, count_only, taps);
 }
 
+size_t vtmo5_run_f64(const vtmo5_config*, double, const float*, size_t, float*, size_t, int*);
+size_t vtmo5_run_f32(const vtmo5_config*, double, const float*, size_t, float*, size_t, int*);
+
+size_t vtmo5_synthesize(const vtmo5_config* cfg, double control_rate, const float* params, size_t n_frames,
+		float* out, size_t out_capacity, int* sample_rate_milli)
+{
+	return cfg->float_model ? vtmo5_run_f32(cfg, control_rate, params, n_frames, out, out_capacity, sample_rate_milli)
+	                        : vtmo5_run_f64(cfg, control_rate, params, n_frames, out, out_capacity, sample_rate_milli);
+}
+
 int vtmo_derive(const vtmo_config* cfg, double control_rate, vtmo_derived* out)
 {
 	return cfg->float_model ? vtmo_derive_f32(cfg, control_rate, out) : vtmo_derive_f64(cfg, control_rate, out);

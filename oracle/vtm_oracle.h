@@ -63,6 +63,26 @@ typedef struct vtmo_config {
 	                                     VocalTractModel2<float,D>, VocalTractModel4<float,1>) */
 } vtmo_config;
 
+/* VocalTractModel5::loadConfiguration (vtm/VocalTractModel5.h:375-421), as numbers. */
+typedef struct vtmo5_config {
+	double output_rate;
+	int    waveform, noise_modulation, bypass, constant_radius_mouth_impedance;
+	double glottal_pulse_tp, glottal_pulse_tn_min, glottal_pulse_tn_max, breathiness;
+	double vocal_tract_length_offset, vocal_tract_length, temperature, loss_factor, mix_offset;
+	double global_radius_coef, global_nasal_radius_coef;
+	double nasal_radius[6];           /* nasal_radius_2 .. nasal_radius_7 */
+	double radius_coef[8];
+	double glottal_noise_cutoff, frication_noise_cutoff, frication_factor, min_glottal_loss, max_glottal_loss,
+	       glottal_lowpass_cutoff, mouth_impedance_radius;
+	int    float_model;
+} vtmo5_config;
+
+/* VocalTractModel5<TFloat,1> (reference model 5) driven by Controller::synthesize: returns the number of
+ * output samples (only out_capacity are stored).  ORACLE ONLY this round: the device path does not serve
+ * model 5 yet.  sample_rate_milli, if non-NULL, receives the internal rate in mHz (it is not an integer). */
+size_t vtmo5_synthesize(const vtmo5_config* cfg, double control_rate, const float* params, size_t n_frames,
+		float* out, size_t out_capacity, int* sample_rate_milli);
+
 /* Design-time quantities derived from the configuration. */
 typedef struct vtmo_derived {
 	int      sample_rate;             /* internal rate (VocalTractModel0.h:344, VocalTractModel2.h:419) */

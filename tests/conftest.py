@@ -25,6 +25,15 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden5():
+    """Reference VocalTractModel5 vectors (tests/golden/make_vtm5_golden.py)."""
+    z = np.load(os.path.join(HERE, "golden", "vtm5_golden.npz"), allow_pickle=False)
+    data = {k: z[k] for k in z.files}
+    data["manifest"] = json.loads(bytes(data.pop("manifest_json")).decode())
+    return data
+
+
+@pytest.fixture(scope="session")
 def golden_tracks():
     """Captured EventList::generateOutput() calls of the reference (tests/golden/make_tracks_golden.py)."""
     z = np.load(os.path.join(HERE, "golden", "tracks_golden.npz"), allow_pickle=False)

@@ -99,6 +99,77 @@ def male_config(output_rate=44100.0, section_delay=1, layout=0, float_model=0, *
     return config_from_dict(d, output_rate, section_delay, layout, float_model)
 
 
+VOICE5_MALE = os.path.join(GOLDEN_DIR, "voice5_male.txt")
+
+
+class Oracle5Config(ctypes.Structure):
+    """vtmo5_config (oracle/vtm_oracle.h): VocalTractModel5's configuration keys as numbers."""
+    _fields_ = [
+        ("output_rate", ctypes.c_double),
+        ("waveform", ctypes.c_int), ("noise_modulation", ctypes.c_int), ("bypass", ctypes.c_int),
+        ("constant_radius_mouth_impedance", ctypes.c_int),
+        ("glottal_pulse_tp", ctypes.c_double), ("glottal_pulse_tn_min", ctypes.c_double),
+        ("glottal_pulse_tn_max", ctypes.c_double), ("breathiness", ctypes.c_double),
+        ("vocal_tract_length_offset", ctypes.c_double), ("vocal_tract_length", ctypes.c_double),
+        ("temperature", ctypes.c_double), ("loss_factor", ctypes.c_double), ("mix_offset", ctypes.c_double),
+        ("global_radius_coef", ctypes.c_double), ("global_nasal_radius_coef", ctypes.c_double),
+        ("nasal_radius", ctypes.c_double * 6),
+        ("radius_coef", ctypes.c_double * 8),
+        ("glottal_noise_cutoff", ctypes.c_double), ("frication_noise_cutoff", ctypes.c_double),
+        ("frication_factor", ctypes.c_double), ("min_glottal_loss", ctypes.c_double),
+        ("max_glottal_loss", ctypes.c_double), ("glottal_lowpass_cutoff", ctypes.c_double),
+        ("mouth_impedance_radius", ctypes.c_double),
+        ("float_model", ctypes.c_int),
+    ]
+
+
+def _flag(v):
+    return 1 if str(v).strip().lower() in ("1", "true") else 0
+
+
+def config5_from_dict(d, output_rate=None, float_model=0):
+    c = Oracle5Config()
+    c.output_rate = float(d["output_rate"]) if output_rate is None else float(output_rate)
+    c.waveform = int(float(d["waveform"]))
+    c.noise_modulation = int(float(d["noise_modulation"]))
+    c.bypass = int(float(d["bypass"]))
+    c.constant_radius_mouth_impedance = _flag(d["constant_radius_mouth_impedance"])
+    for k in ("glottal_pulse_tp", "glottal_pulse_tn_min", "glottal_pulse_tn_max", "breathiness",
+              "vocal_tract_length_offset", "vocal_tract_length", "temperature", "loss_factor", "mix_offset",
+              "global_radius_coef", "global_nasal_radius_coef", "glottal_noise_cutoff", "frication_noise_cutoff",
+              "frication_factor", "min_glottal_loss", "max_glottal_loss", "glottal_lowpass_cutoff",
+              "mouth_impedance_radius"):
+        setattr(c, k, float(d[k]))
+    for i in range(6):
+        c.nasal_radius[i] = float(d["nasal_radius_%d" % (i + 2)])
+    for i in range(8):
+        c.radius_coef[i] = float(d["radius_%d_coef" % (i + 1)])
+    c.float_model = int(float_model)
+    return c
+
+
+def male5_config(output_rate=48000.0, float_model=0, **overrides):
+    d = read_config_file(VOICE5_MALE)
+    d.update({k: str(v) for k, v in overrides.items()})
+    return config5_from_dict(d, output_rate, float_model)
+
+
+def synthesize5(cfg, params, control_rate=250.0):
+    """VocalTractModel5 restatement (oracle only): float32 [F][16] -> (float32 [N], internal rate in Hz)."""
+    L = lib()
+    L.vtmo5_synthesize.argtypes = [ctypes.POINTER(Oracle5Config), ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t,
+                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.vtmo5_synthesize.restype = ctypes.c_size_t
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    assert params.ndim == 2 and params.shape[1] == 16
+    rate = ctypes.c_int(0)
+    n = L.vtmo5_synthesize(ctypes.byref(cfg), control_rate, params.ctypes.data, params.shape[0], None, 0, ctypes.byref(rate))
+    out = np.empty(n, dtype=np.float32)
+    got = L.vtmo5_synthesize(ctypes.byref(cfg), control_rate, params.ctypes.data, params.shape[0], out.ctypes.data, n, None)
+    assert got == n, (got, n)
+    return out, rate.value / 1000.0
+
+
 _lib = None
 
 
