@@ -9,6 +9,7 @@ from .capi import (  # noqa: F401
     GvtmError,
     Plan,
     TrackConfig,
+    config5_from_dict,
     config_from_dict,
     device_count,
     library_path,

@@ -67,6 +67,30 @@ class Info(ctypes.Structure):
         ("device", ctypes.c_int32),
         ("precision", ctypes.c_int32),
         ("section_delay", ctypes.c_int32),
+        ("model5", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
+        ("internal_rate_hz", ctypes.c_double),
+    ]
+
+
+class Config5(ctypes.Structure):
+    """gvtm5_config: VocalTractModel5's configuration keys (reference model 5)."""
+    _fields_ = [
+        ("output_rate", ctypes.c_double),
+        ("waveform", ctypes.c_int32), ("noise_modulation", ctypes.c_int32), ("bypass", ctypes.c_int32),
+        ("constant_radius_mouth_impedance", ctypes.c_int32),
+        ("glottal_pulse_tp", ctypes.c_double), ("glottal_pulse_tn_min", ctypes.c_double),
+        ("glottal_pulse_tn_max", ctypes.c_double), ("breathiness", ctypes.c_double),
+        ("vocal_tract_length_offset", ctypes.c_double), ("vocal_tract_length", ctypes.c_double),
+        ("temperature", ctypes.c_double), ("loss_factor", ctypes.c_double), ("mix_offset", ctypes.c_double),
+        ("global_radius_coef", ctypes.c_double), ("global_nasal_radius_coef", ctypes.c_double),
+        ("nasal_radius", ctypes.c_double * 6),
+        ("radius_coef", ctypes.c_double * 8),
+        ("glottal_noise_cutoff", ctypes.c_double), ("frication_noise_cutoff", ctypes.c_double),
+        ("frication_factor", ctypes.c_double), ("min_glottal_loss", ctypes.c_double),
+        ("max_glottal_loss", ctypes.c_double), ("glottal_lowpass_cutoff", ctypes.c_double),
+        ("mouth_impedance_radius", ctypes.c_double),
+        ("precision", ctypes.c_int32), ("reserved_", ctypes.c_int32),
     ]
 
 
@@ -102,6 +126,8 @@ def load_library():
     L.gvtm_device_count.restype = i32
     L.gvtm_plan_create.argtypes = [ctypes.POINTER(Config), dbl, i32, ctypes.POINTER(vp)]
     L.gvtm_plan_create.restype = i32
+    L.gvtm_plan_create_model5.argtypes = [ctypes.POINTER(Config5), dbl, i32, ctypes.POINTER(vp)]
+    L.gvtm_plan_create_model5.restype = i32
     L.gvtm_plan_destroy.argtypes = [vp]
     L.gvtm_plan_destroy.restype = None
     L.gvtm_plan_info.argtypes = [vp, ctypes.POINTER(Info)]
@@ -166,6 +192,27 @@ def config_from_dict(d, output_rate=None, section_delay=1, precision=PRECISION_F
     c.section_delay = int(section_delay)
     c.precision = int(precision)
     c.tube_layout = int(tube_layout)
+    return c
+
+
+def config5_from_dict(d, output_rate=None, precision=PRECISION_F64):
+    """Builds a gvtm5_config from the merged vtm.txt + variant keys of a model-5 voice (VocalTractModel5.h:375-421)."""
+    c = Config5()
+    c.output_rate = float(d["output_rate"]) if output_rate is None else float(output_rate)
+    for key in ("waveform", "noise_modulation", "bypass"):
+        setattr(c, key, int(float(d[key])))
+    c.constant_radius_mouth_impedance = 1 if str(d["constant_radius_mouth_impedance"]).strip().lower() in ("1", "true") else 0
+    for key in ("glottal_pulse_tp", "glottal_pulse_tn_min", "glottal_pulse_tn_max", "breathiness",
+                "vocal_tract_length_offset", "vocal_tract_length", "temperature", "loss_factor", "mix_offset",
+                "global_radius_coef", "global_nasal_radius_coef", "glottal_noise_cutoff", "frication_noise_cutoff",
+                "frication_factor", "min_glottal_loss", "max_glottal_loss", "glottal_lowpass_cutoff"):
+        setattr(c, key, float(d[key]))
+    c.mouth_impedance_radius = float(d.get("mouth_impedance_radius", 0.0))
+    for i in range(6):
+        c.nasal_radius[i] = float(d["nasal_radius_%d" % (i + 2)])
+    for i in range(8):
+        c.radius_coef[i] = float(d["radius_%d_coef" % (i + 1)])
+    c.precision = int(precision)
     return c
 
 
@@ -253,7 +300,8 @@ class Plan:
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         self.config = config
-        rc = self._lib.gvtm_plan_create(ctypes.byref(config), float(control_rate), int(device), ctypes.byref(self._h))
+        create = self._lib.gvtm_plan_create_model5 if isinstance(config, Config5) else self._lib.gvtm_plan_create
+        rc = create(ctypes.byref(config), float(control_rate), int(device), ctypes.byref(self._h))
         self._check(rc)
         info = Info()
         self._check(self._lib.gvtm_plan_info(self._h, ctypes.byref(info)))

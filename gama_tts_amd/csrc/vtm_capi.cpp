@@ -70,6 +70,7 @@ struct gvtm_plan {
 	void* d_src_h = nullptr;
 	void* d_src_dh = nullptr;
 	gvtm::DeviceConstants* d_consts = nullptr;
+	gvtm::Model5Constants* d_consts5 = nullptr; // model 5 plans only
 	// staging for the host-buffer entry point
 	DeviceBuffer s_params, s_frames, s_audio, s_counts, s_maxabs;
 	// kernel timing (HIP events on the launch stream)
@@ -103,6 +104,7 @@ void free_plan(gvtm_plan* p)
 	if (p->d_src_h) (void) hipFree(p->d_src_h);
 	if (p->d_src_dh) (void) hipFree(p->d_src_dh);
 	if (p->d_consts) (void) hipFree(p->d_consts);
+	if (p->d_consts5) (void) hipFree(p->d_consts5);
 	p->s_params.release();
 	p->s_frames.release();
 	p->s_audio.release();
@@ -195,6 +197,45 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 	}
 }
 
+int gvtm_plan_create_model5(const gvtm5_config* config, double control_rate, int device, gvtm_plan** plan_out)
+{
+	if (!config || !plan_out) return fail(GVTM_ERR_INVALID_ARGUMENT, "null config or plan_out");
+	*plan_out = nullptr;
+	try {
+		std::unique_ptr<gvtm_plan, void (*)(gvtm_plan*)> plan(new gvtm_plan, free_plan);
+		const std::string why = gvtm::design_plan5(*config, control_rate, plan->design);
+		if (!why.empty()) return fail(GVTM_ERR_INVALID_ARGUMENT, why);
+		plan->precision = GVTM_PRECISION_F64;
+		if (device == GVTM_DEVICE_NONE) {
+			plan->device = GVTM_DEVICE_NONE;
+			*plan_out = plan.release();
+			return GVTM_OK;
+		}
+		int n = 0;
+		hipError_t e = hipGetDeviceCount(&n);
+		if (e != hipSuccess || n <= 0) return fail(GVTM_ERR_NO_DEVICE, "no HIP device available (libgama_vtm has no CPU path)");
+		if (device < 0 || device >= n) return fail(GVTM_ERR_NO_DEVICE, "device index out of range");
+		plan->device = device;
+		if ((e = hipSetDevice(device)) != hipSuccess) return fail_hip(e, "hipSetDevice");
+		hipDeviceProp_t prop;
+		if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail_hip(e, "hipGetDeviceProperties");
+		if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+			return fail(GVTM_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+		}
+		const gvtm::Design& dg = plan->design;
+		if ((e = upload(&plan->d_src_h, dg.src_h)) != hipSuccess) return fail_hip(e, "upload src_h");
+		if ((e = upload(&plan->d_src_dh, dg.src_dh)) != hipSuccess) return fail_hip(e, "upload src_dh");
+		if ((e = upload(&plan->d_consts, std::vector<gvtm::DeviceConstants>(1, dg.k))) != hipSuccess) return fail_hip(e, "upload constants");
+		if ((e = upload(&plan->d_consts5, std::vector<gvtm::Model5Constants>(1, dg.k5))) != hipSuccess) return fail_hip(e, "upload model 5 constants");
+		*plan_out = plan.release();
+		return GVTM_OK;
+	} catch (const std::bad_alloc&) {
+		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
+	} catch (const std::exception& ex) {
+		return fail(GVTM_ERR_INVALID_ARGUMENT, ex.what());
+	}
+}
+
 void gvtm_plan_destroy(gvtm_plan* plan)
 {
 	free_plan(plan);
@@ -216,6 +257,9 @@ int gvtm_plan_info(const gvtm_plan* plan, gvtm_info* info)
 	info->device = plan->device;
 	info->precision = plan->precision;
 	info->section_delay = k.section_delay;
+	info->model5 = plan->design.model5 ? 1 : 0;
+	info->reserved_ = 0;
+	info->internal_rate_hz = plan->design.model5 ? plan->design.k5.sample_rate : static_cast<double>(k.sample_rate);
 	return GVTM_OK;
 }
 
@@ -230,6 +274,7 @@ int gvtm_plan_table(const gvtm_plan* plan, int which, double* out, size_t capaci
 	case GVTM_TABLE_WAVETABLE: src = &plan->design.wavetable; break;
 	default: return -fail(GVTM_ERR_INVALID_ARGUMENT, "unknown table");
 	}
+	if (src->empty()) return -fail(GVTM_ERR_INVALID_ARGUMENT, "this model has no such table");
 	if (capacity < src->size()) return -fail(GVTM_ERR_INVALID_ARGUMENT, "table buffer too small");
 	std::memcpy(out, src->data(), sizeof(double) * src->size());
 	return static_cast<int>(src->size());
@@ -442,8 +487,11 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	if (audio_stride < need) {
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
 	}
-	const int rows = gvtm::synth_rows(plan->precision, batch, plan->rows);
-	if (gvtm::synth_lds_bytes(plan->precision, plan->generation, rows) > 160 * 1024) return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
+	const bool model5 = plan->design.model5;
+	const int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows);
+	if ((model5 ? gvtm::synth5_lds_bytes() : gvtm::synth_lds_bytes(plan->precision, plan->generation, rows)) > 160 * 1024) {
+		return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
+	}
 
 	hipError_t e = hipSetDevice(plan->device);
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
@@ -466,6 +514,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	args.batch = batch;
 	args.debug_taps = plan->debug_taps;
 	args.phase_cycles = plan->phase_cycles;
+	args.k5const = plan->d_consts5;
 
 	EventPair ev;
 	if (plan->timing) {
@@ -478,7 +527,8 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 		}
 		if ((e = hipEventRecord(ev.start, stream)) != hipSuccess) return fail_hip(e, "hipEventRecord");
 	}
-	e = gvtm::launch_synth(args, batch, plan->precision, plan->generation, rows, stream);
+	e = model5 ? gvtm::launch_synth5(args, batch, stream)
+	           : gvtm::launch_synth(args, batch, plan->precision, plan->generation, rows, stream);
 	if (plan->timing) {
 		(void) hipEventRecord(ev.stop, stream);
 		plan->pending.push_back(ev);

@@ -348,6 +348,153 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 	return "";
 }
 
+void radiation_impedance(double radius, double period, double out[6])
+{
+	const double transition = 0.5e-2;
+	const double rr = radius < transition ? transition : radius;
+	const double trans_freq = 62.3371 / rr + 320.204;
+	const double cos_wt = std::cos((2.0 * kPi) * trans_freq * period);
+	const double qa = 2.0 * cos_wt;
+	const double qb = -2.0 * (cos_wt + 1.0);
+	const double qc = cos_wt + 1.0;
+	const double delta = qb * qb - 4.0 * qa * qc;
+	double a = (-qb - std::sqrt(delta)) / (2.0 * qa);
+	const double b = 2.0 * a - 1.0;
+	if (radius < transition) a *= 40391.2 * (radius * radius);
+	const double coef = 1.0 / (a + 1.0);
+	const double a_plus_b = a + b;
+	out[0] = a_plus_b * coef;
+	out[1] = 2.0 * coef;
+	out[2] = -2.0 * b * coef;
+	out[3] = a_plus_b * coef;
+	out[4] = (a - 1.0) * coef;
+	out[5] = (b - a) * coef;
+}
+
+// VocalTractModel5: loadConfiguration (vtm/VocalTractModel5.h:375-421) and initializeSynthesizer (:455-521)
+// with TFloat = double, the checks its constructors make included.
+std::string design_plan5(const gvtm5_config& c, double control_rate, Design& out)
+{
+	std::ostringstream err;
+	auto finite_pos = [](double v) { return std::isfinite(v) && v > 0.0; };
+	if (!finite_pos(c.output_rate)) return "output_rate must be > 0";
+	if (!finite_pos(control_rate)) return "control_rate must be > 0";
+	if (c.precision != GVTM_PRECISION_F64) return "model 5 computes in fp64 only (VocalTractModel5<double,1>)";
+	if (c.reserved_ != 0) return "reserved_ must be 0";
+	if (c.waveform != 0 && c.waveform != 1) return "waveform must be 0 (pulse) or 1 (sine)";
+	if (!(c.temperature > -273.0) || !std::isfinite(c.temperature)) return "temperature out of range";
+
+	out.model5 = true;
+	out.config5 = c;
+	out.config = gvtm_config{};
+	out.config.output_rate = c.output_rate;
+	out.control_rate = control_rate;
+	out.f32 = false;
+	DeviceConstants& k = out.k;
+	Model5Constants& m = out.k5;
+	k = DeviceConstants{};
+	m = Model5Constants{};
+	k.section_delay = 1;
+	k.layout = 2;
+	k.waveform = c.waveform;
+	k.modulation = c.noise_modulation != 0;
+	m.bypass = c.bypass == 1;
+	m.constant_mouth = c.constant_radius_mouth_impedance != 0;
+	m.output_rate = c.output_rate;
+
+	double length = c.vocal_tract_length_offset + c.vocal_tract_length;
+	length = std::min(std::max(length, 3.0), 30.0);
+	double nasal[7] = {0.0};
+	for (int i = 0; i < 6; ++i) {
+		nasal[i + 1] = c.nasal_radius[i] * c.global_nasal_radius_coef;
+		if (!finite_pos(nasal[i + 1])) return "nasal radii must be > 0";
+	}
+	for (int i = 0; i < 8; ++i) k.radius_coef[i] = c.radius_coef[i] * c.global_radius_coef;
+
+	const double speed = 331.4 + (0.6 * c.temperature);
+	m.sample_rate = (speed * (30 * 1) * 100.0f) / length;
+	// PoleZeroRadiationImpedance's constructor (vtm/PoleZeroRadiationImpedance.h:116-119)
+	if (!(m.sample_rate >= 50000.0)) return "model 5 needs an internal rate of at least 50 kHz (vocal tract too long / too cold)";
+	k.sample_rate = static_cast<int>(m.sample_rate);
+	k.breathiness = c.breathiness / 100.0f;
+	const double mix_amp = amplitude_60db_t<double>(c.mix_offset);
+	if (!(mix_amp > 0.0)) return "mix_offset must be > 0 dB";
+	k.crossmix_factor = 1.0f / mix_amp;
+	k.damping = 1.0f - (c.loss_factor / 100.0f);
+
+	// RosenbergBGlottalSource's constructor (vtm/RosenbergBGlottalSource.h:66-96)
+	m.rb_tn_min = c.glottal_pulse_tn_min / 100.0f;
+	m.rb_tn_max = c.glottal_pulse_tn_max / 100.0f;
+	m.rb_t1 = c.glottal_pulse_tp / 100.0f;
+	if (!(m.rb_t1 >= 1.0e-2) || !(m.rb_tn_min >= 1.0e-2) || !(m.rb_tn_max >= 1.0e-2) || m.rb_tn_min > m.rb_tn_max ||
+			m.rb_t1 + m.rb_tn_max > 1.0) {
+		return "glottal pulse shape needs tp, tn_min, tn_max >= 1 %, tn_min <= tn_max, tp + tn_max <= 100";
+	}
+
+	m.period = 1.0f / m.sample_rate;
+	if (m.constant_mouth) radiation_impedance(c.mouth_impedance_radius * 1.0e-2f, m.period, m.mouth_c);
+	// initializeNasalCavity (vtm/VocalTractModel5.h:593-603)
+	for (int i = 1; i < 6; ++i) m.nasal_k[i] = junction<double>(nasal[i], nasal[i + 1]);
+	radiation_impedance(std::sqrt(0.5f * nasal[6] * nasal[6]) * 1.0e-2f, m.period, m.nose_c);
+	m.nasal_r1_sq = nasal[1] * nasal[1];
+
+	// Butterworth filters (their update() range checks included)
+	auto butter_ok = [&](double cutoff) { return cutoff >= 1.0 && cutoff <= m.sample_rate * 0.48; };
+	if (!butter_ok(c.glottal_noise_cutoff) || !butter_ok(c.frication_noise_cutoff) || !butter_ok(c.glottal_lowpass_cutoff)) {
+		return "Butterworth cutoffs must lie between 1 Hz and 0.48 of the internal rate";
+	}
+	auto butter1 = [&](double cutoff, double& b0, double& a1) {
+		const double wcT = 2.0 * std::tan(kPi * cutoff / m.sample_rate);
+		const double c1 = 1.0 / (wcT + 2.0);
+		b0 = c1 * wcT;
+		a1 = c1 * (wcT - 2.0);
+	};
+	butter1(c.glottal_noise_cutoff, m.gn_b0, m.gn_a1);
+	butter1(c.glottal_lowpass_cutoff, m.gp_b0, m.gp_a1);
+	{
+		const double wcT = 2.0 * std::tan(kPi * c.frication_noise_cutoff / m.sample_rate);
+		const double wc2T2 = wcT * wcT;
+		const double c1 = 2.0 * std::sqrt(2.0) * wcT;
+		const double c2 = 1.0 / (wc2T2 + c1 + 4.0);
+		m.fn_b0 = c2 * wc2T2;
+		m.fn_b1 = 2.0 * m.fn_b0;
+		m.fn_a1 = c2 * (2.0 * wc2T2 - 8.0);
+		m.fn_a2 = c2 * (wc2T2 - c1 + 4.0);
+	}
+	m.frication_factor = c.frication_factor;
+	m.min_loss = c.min_glottal_loss / 100.0f;
+	m.max_loss = c.max_glottal_loss / 100.0f;
+	k.bp_T = 1.0 / m.sample_rate; // BandpassFilter::update (BandpassFilter.h:104)
+
+	// Controller::synthesize (vtm_control_model/Controller.cpp:286-287)
+	k.control_steps = static_cast<unsigned>(std::rint(m.sample_rate / control_rate));
+	if (k.control_steps == 0) return "control_rate above the internal sample rate";
+	k.interp_coef = 1.0f / k.control_steps;
+
+	// SampleRateConverter::initializeConversion (vtm/SampleRateConverter.h:136-164)
+	const double ratio = c.output_rate / m.sample_rate;
+	k.src_ratio = ratio;
+	k.time_inc = static_cast<unsigned>(std::rint(std::pow(2.0, 16) / ratio));
+	if (k.time_inc == 0) return "output_rate too high for the 16.16 time register";
+	const double rounded_ratio = std::pow(2.0, 16) / k.time_inc;
+	k.upsampling = ratio >= 1.0;
+	if (k.upsampling) {
+		k.phase_inc = 0;
+		k.pad = kSrcZeroCrossings;
+	} else {
+		k.phase_inc = static_cast<unsigned>(std::rint(ratio * 65536));
+		k.pad = static_cast<int>(kSrcZeroCrossings / rounded_ratio) + 1;
+	}
+	if (k.pad > kMaxPad || (k.phase_inc == 0 && !k.upsampling)) {
+		err << "output_rate / internal rate = " << ratio << " is below the supported down-sampling range";
+		return err.str();
+	}
+	design_src_filter<double>(out.src_h, out.src_dh);
+	out.fir.clear();
+	out.wavetable.clear();
+	return "";
+}
+
 bool output_count_for_steps(const DeviceConstants& k, uint64_t steps, uint64_t& n_out)
 {
 	// An output sample k is emitted while its integer read position

@@ -57,7 +57,29 @@ struct DeviceConstants {
 	double src_ratio;         // sampleRateRatio_
 };
 
+// VocalTractModel5 only: what initializeSynthesizer (vtm/VocalTractModel5.h:455-521) derives besides the numbers
+// shared with the other models (rates, driver loop, radius coefficients, damping, resampler in DeviceConstants)
+struct Model5Constants {
+	double sample_rate;        // sampleRate_ (TFloat, not truncated)
+	double output_rate;
+	int bypass, constant_mouth;
+	double rb_t1, rb_tn_min, rb_tn_max;      // RosenbergBGlottalSource (vtm/RosenbergBGlottalSource.h:66-96)
+	double gn_b0, gn_a1;                     // glottal-noise Butterworth1 (vtm/Butterworth1LowpassFilter.h:63-76)
+	double gp_b0, gp_a1;                     // glottal-pulse Butterworth1
+	double fn_b0, fn_b1, fn_a1, fn_a2;       // frication-noise Butterworth2 (vtm/Butterworth2LowpassFilter.h:88-107)
+	double frication_factor;
+	double min_loss, max_loss;               // min/max_glottal_loss / 100
+	double nasal_r1_sq;                      // nasalRadius[NR2]^2: right side of the first nasal junction
+	double nasal_k[6];                       // [1..5]: fixed nasal junctions NJ2..NJ6; [0] unused (time varying)
+	double period;                           // PoleZeroRadiationImpedance::samplePeriod_
+	double nose_c[6];                        // cT1, cT2, cT3, cR1, cR2, cR3 at the nose (fixed radius)
+	double mouth_c[6];                       // the same at the mouth when its radius is constant
+};
+
 struct Design {
+	bool model5 = false;
+	gvtm5_config config5{};
+	Model5Constants k5{};
 	gvtm_config config;
 	double control_rate;
 	DeviceConstants k;
@@ -72,6 +94,11 @@ struct Design {
 
 // Returns "" on success, otherwise a description of the offending value.
 std::string design_plan(const gvtm_config& cfg, double control_rate, Design& out);
+
+std::string design_plan5(const gvtm5_config& cfg, double control_rate, Design& out);
+
+// PoleZeroRadiationImpedance::update (vtm/PoleZeroRadiationImpedance.h:139-177): radius in metres -> cT1..3, cR1..3
+void radiation_impedance(double radius, double period, double out[6]);
 
 // Util::amplitude60dB (vtm/VTMUtil.h:48-67)
 double amplitude_60db(double db);

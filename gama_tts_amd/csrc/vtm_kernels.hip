@@ -42,6 +42,7 @@ namespace {
 
 #include "vtm_kernel_v1.inc"
 #include "vtm_kernel_v2.inc"
+#include "vtm_kernel_m5.inc"
 
 // Controller::writeOutputToBuffer / writeOutputToFile (Controller.cpp:315-340): scale by
 // 0.95 / max|x| (Util::calculateOutputScale, VTMUtil.cpp:48-67); the int16 form rounds as
@@ -227,6 +228,25 @@ hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int 
 	if (precision == GVTM_PRECISION_F32) return launch_v2_rows<float, float>(args, batch, rows, stream);
 	if (mixed) return launch_v2_rows<double, float>(args, batch, rows, stream);
 	return launch_v2_rows<double, double>(args, batch, rows, stream);
+}
+
+// reference model 5: chunk of 60 steps (one 64-lane pass per per-step stage), three helper wavefronts
+constexpr int kM5Chunk = 60, kM5Helpers = 3, kM5Ring = 512;
+
+size_t synth5_lds_bytes()
+{
+	return m5::Offsets<kM5Chunk, kM5Ring>().total;
+}
+
+hipError_t launch_synth5(const SynthArgs& args, size_t batch, hipStream_t stream)
+{
+	if (!args.k5const) return hipErrorInvalidValue;
+	auto fn = m5::vtm5_synth_kernel<kM5Chunk, kM5Helpers, kM5Ring>;
+	const size_t lds = synth5_lds_bytes();
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(batch)), dim3((4 + kM5Helpers) * 64), lds, stream, args);
+	return hipGetLastError();
 }
 
 // Test hook: the all-float path's per-step conversions evaluated ON THE DEVICE

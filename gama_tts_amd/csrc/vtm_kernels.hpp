@@ -31,6 +31,7 @@ struct SynthArgs {
 	size_t batch;
 	double* debug_taps;          // null, or [batch][max_frames*control_steps][8] per-step taps (tests only)
 	unsigned long long* phase_cycles; // null, or [batch][8] shader cycles spent per phase (diagnostics only)
+	const Model5Constants* k5const = nullptr; // model 5 only: its constants in device memory
 };
 
 struct NormalizeArgs {
@@ -50,6 +51,9 @@ struct NormalizeArgs {
 int synth_rows(int precision, size_t batch, int requested);
 size_t synth_lds_bytes(int precision, int generation, int rows);
 hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int generation, int rows, hipStream_t stream);
+// reference model 5 (VocalTractModel5<double,1>): one utterance per workgroup, fp64
+size_t synth5_lds_bytes();
+hipError_t launch_synth5(const SynthArgs& args, size_t batch, hipStream_t stream);
 constexpr int kDppSelftestInts = 640;
 hipError_t launch_dpp_selftest(int* d_out /* [kDppSelftestInts] */, hipStream_t stream);
 hipError_t launch_float_math_probe(int kind, const float* d_x, size_t n, float* d_out, hipStream_t stream);

@@ -13,6 +13,8 @@
  *                               initializeSynthesizer (vtm/VocalTractModel0.h:255-305, :338-392;
  *                               vtm/VocalTractModel2.h:322-376, :413-467; vtm/VocalTractModel4.h:370-515)
  *                               for a whole batch
+ *   gvtm_plan_create_model5     VocalTractModel5 constructor (vtm/VocalTractModel5.h:375-421, :455-521); synthesis
+ *                               then replaces its execSynthesisStep / vocalTract (:523-579, :632-730)
  *   gvtm_plan_info              VocalTractModel::internalSampleRate/outputSampleRate
  *                               (vtm/VocalTractModel.h:51-52) and the controlSteps of
  *                               Controller::synthesize (vtm_control_model/Controller.cpp:286)
@@ -114,7 +116,45 @@ typedef struct gvtm_info {
 	int32_t device;
 	int32_t precision;
 	int32_t section_delay;
+	int32_t model5;                   /* 1 for a plan made by gvtm_plan_create_model5 */
+	int32_t reserved_;
+	double internal_rate_hz;          /* the internal rate as the model holds it: an integer for models 0-4, not for
+	                                     model 5 (vtm/VocalTractModel5.h:465 keeps it in TFloat) */
 } gvtm_info;
+
+/* The configuration keys VocalTractModel5::loadConfiguration reads (vtm/VocalTractModel5.h:375-421), as numbers:
+ * reference model 5 — 30 + 21 sections with flow junctions, Rosenberg B glottal source, pole-zero radiation
+ * impedance at mouth and nose, Butterworth noise/source filters, glottal loss, differentiated output. */
+typedef struct gvtm5_config {
+	double output_rate;
+	int32_t waveform;                         /* 0 pulse, 1 sine */
+	int32_t noise_modulation;
+	int32_t bypass;                           /* 1: the glottal signal goes straight to the resampler (:566-568) */
+	int32_t constant_radius_mouth_impedance;  /* 0: the mouth impedance follows r8 every step */
+	double glottal_pulse_tp;
+	double glottal_pulse_tn_min;
+	double glottal_pulse_tn_max;
+	double breathiness;
+	double vocal_tract_length_offset;
+	double vocal_tract_length;
+	double temperature;
+	double loss_factor;
+	double mix_offset;
+	double global_radius_coef;
+	double global_nasal_radius_coef;
+	double nasal_radius[6];                   /* nasal_radius_2 .. nasal_radius_7 */
+	double radius_coef[8];
+	double glottal_noise_cutoff;
+	double frication_noise_cutoff;
+	double frication_factor;
+	double min_glottal_loss;
+	double max_glottal_loss;
+	double glottal_lowpass_cutoff;
+	double mouth_impedance_radius;            /* used when constant_radius_mouth_impedance != 0 */
+	int32_t precision;                        /* GVTM_PRECISION_F64 only: the factory's model 5 is VocalTractModel5<double,1>
+	                                             (vtm/VocalTractModel.cpp:47-48) */
+	int32_t reserved_;                        /* must be 0 */
+} gvtm5_config;
 
 typedef struct gvtm_plan gvtm_plan;
 
@@ -139,6 +179,10 @@ int gvtm_device_count(void);
 /* Validates the configuration, designs the tables on the host (fp64) and uploads them to
  * `device`.  control_rate is 1000 / control_period Hz (VTMControlModelConfiguration.cpp:41). */
 int gvtm_plan_create(const gvtm_config* config, double control_rate, int device, gvtm_plan** plan_out);
+/* The same for reference model 5 (VocalTractModel5 constructor: loadConfiguration + initializeSynthesizer,
+ * vtm/VocalTractModel5.h:375-421, :455-521).  The plan is used with the same synthesis entry points;
+ * gvtm_plan_table() serves the resampler tables only. */
+int gvtm_plan_create_model5(const gvtm5_config* config, double control_rate, int device, gvtm_plan** plan_out);
 void gvtm_plan_destroy(gvtm_plan* plan);
 int gvtm_plan_info(const gvtm_plan* plan, gvtm_info* info_out);
 /* Copies a design table into out[capacity]; returns the element count or a negative status. */

@@ -1,0 +1,109 @@
+"""Parity of the device path for reference model 5 (VocalTractModel5<double,1>) with the reference vectors
+(tests/golden/vtm5_golden.npz) and the oracle, through the C ABI.
+
+Tolerance.  Both sides compute in fp64 and differ at the 1e-13 level (device libm, fused multiply-adds); the
+resampler's output is rounded to float32 and THEN differenced and multiplied by the output rate
+(VocalTractModel5.h:507-513), so a float32 sample whose rounding flips (one ulp, 6e-8 of the sample) turns into
+an output error of ulp * output_rate, a few 1e-7 of the output's peak.  The bar: every sample within
+TOL = 2e-6 of the utterance's peak, at least 90 % of the samples bit-identical, sample counts exact.  In bypass
+mode (no difference filter) the bar is the fp64 path's of the other models: 1e-9 of peak or one float32 ulp.
+"""
+import numpy as np
+import pytest
+
+import gama_tts_amd as g
+from gama_tts_amd import capi
+import golden5_cases
+import oracle
+import tracks
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+MIN_EXACT = 0.90
+
+
+def _plan(overrides=None, rate=48000.0, crate=250.0):
+    d = g.read_config_file(oracle.VOICE5_MALE)
+    d.update({k: str(v) for k, v in (overrides or {}).items()})
+    return g.Plan(g.config5_from_dict(d, rate), crate, 0)
+
+
+def _check(got, ref, bypass=False, peak=None):
+    assert got.shape == ref.shape
+    ref64 = ref.astype(np.float64)
+    peak = float(np.abs(ref64).max()) if peak is None else float(peak)
+    d = np.abs(got.astype(np.float64) - ref64)
+    if bypass:
+        ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+        assert (d <= np.maximum(ulp, 1e-9 * peak)).all(), float(d.max() / max(peak, 1e-300))
+    else:
+        assert float(d.max()) <= TOL * max(peak, 1e-300), float(d.max() / max(peak, 1e-300))
+        if got.size >= 200:
+            assert float((got == ref).mean()) >= MIN_EXACT, float((got == ref).mean())
+
+
+DOUBLE_CASES = [c for c in golden5_cases.CASES if not c["float_model"]]
+
+
+@pytest.mark.parametrize("case", DOUBLE_CASES, ids=lambda c: c["name"])
+def test_reference_vectors(case, golden, golden5):
+    m = golden5["manifest"][case["name"]]
+    tr = golden5_cases.track_for(case, golden)
+    plan = _plan(case["overrides"], case["rate"], case["crate"])
+    assert plan.info.model5 == 1
+    assert abs(plan.info.internal_rate_hz - m["fs"]) < 1e-6
+    assert plan.info.control_steps * tr.shape[0] == m["steps"]
+    assert plan.output_count(tr.shape[0]) == m["n"]
+    audio, counts, maxabs = plan.synthesize_host(tr[None])
+    assert counts[0] == m["n"]
+    out = audio[0]
+    bypass = int(case["overrides"].get("bypass", 0)) == 1
+    if case["store"] == "full":
+        _check(out, golden5[case["name"] + "__out"], bypass, m["maxabs"])
+    else:
+        _check(out[:: golden5_cases.DIGEST_STRIDE], golden5[case["name"] + "__strided"], bypass, m["maxabs"])
+    assert maxabs[0] == pytest.approx(m["maxabs"], rel=10 * TOL, abs=1e-12)
+    assert maxabs[0] == np.abs(out).max()
+
+
+def test_ragged_batch_against_oracle():
+    # utterances of different lengths in one launch (0, 1, 2, ... frames), consonant-heavy tracks
+    frames = [0, 1, 2, 3, 7, 25, 40, 40, 13, 31]
+    params = tracks.random_tracks(len(frames), 40, seed0=900, consonant_heavy=True)
+    plan = _plan()
+    audio, counts, maxabs = plan.synthesize_host(params, frame_counts=frames)
+    cfg = oracle.male5_config(48000.0)
+    for b, f in enumerate(frames):
+        ref, _ = oracle.synthesize5(cfg, params[b, :f])
+        assert counts[b] == ref.size
+        _check(audio[b, : ref.size], ref)
+        assert maxabs[b] == np.abs(audio[b, : ref.size]).max()
+
+
+def test_batch_of_identical_tracks_is_identical():
+    one = tracks.random_track(30, 77, True)
+    params = np.repeat(one[None], 70, axis=0)
+    audio, _, _ = _plan().synthesize_host(params)
+    assert (audio == audio[0]).all()
+
+
+def test_upsampling_branch():
+    # 96 kHz output is above the 60.4 kHz internal rate: the resampler's other branch (SampleRateConverter.h:320-360)
+    tr = tracks.random_track(30, 5, True)
+    plan = _plan(rate=96000.0)
+    assert plan.info.upsampling == 1
+    audio, counts, _ = plan.synthesize_host(tr[None])
+    ref, _ = oracle.synthesize5(oracle.male5_config(96000.0), tr)
+    assert counts[0] == ref.size
+    _check(audio[0, : ref.size], ref)
+
+
+def test_rejects_what_the_reference_rejects():
+    d = g.read_config_file(oracle.VOICE5_MALE)
+    with pytest.raises(g.GvtmError):  # PoleZeroRadiationImpedance: internal rate below 50 kHz
+        g.Plan(g.config5_from_dict(dict(d, vocal_tract_length="25.0")), 250.0, 0)
+    with pytest.raises(g.GvtmError):  # RosenbergBGlottalSource: tn_min > tn_max
+        g.Plan(g.config5_from_dict(dict(d, glottal_pulse_tn_min="30.0")), 250.0, 0)
+    with pytest.raises(g.GvtmError):  # the factory only offers VocalTractModel5<double,1>
+        g.Plan(g.config5_from_dict(d, precision=capi.PRECISION_F32), 250.0, 0)
