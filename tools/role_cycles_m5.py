@@ -31,7 +31,7 @@ for rep in range(2):
     ms, _ = plan.take_kernel_ms()
 cyc = d_cyc.cpu().numpy().astype(np.float64)
 steps = frames * plan.info.control_steps
-names = ["T tube", "S scan", "F filters", "I interp", "H0", "H1", "H2", "H3", "H4", "H5"]
+names = ["w0", "w1", "w2", "w3", "w4", "w5", "w6", "st A2", "st A1a", "st A1b", "st P6", "st B", "st M", "st N", "st X", "st P7"]
 print("model 5 batch %d frames %d: kernel %.3f ms = %.1f ns/step" % (batch, frames, ms, ms * 1e6 / steps))
 for i, nm in enumerate(names):
     if cyc[:, i].max() > 0:
