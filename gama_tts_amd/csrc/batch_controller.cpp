@@ -57,7 +57,7 @@ gvtm_config config_from_keys(const std::map<std::string, std::string>& k, int pr
 	case 4: c.section_delay = 1; c.tube_layout = GVTM_TUBE_30_18; break;
 	default:
 		throw std::runtime_error("vocal tract model " + std::to_string(model) +
-				" is not served by the device path (supported: 0, 1, 2, 3, 4)");
+				" is not served by the device path (supported: 0, 1, 2, 3, 4, 5)");
 	}
 	if (k.count("section_delay")) c.section_delay = static_cast<int>(num(k, "section_delay"));
 	c.precision = precision;
@@ -85,15 +85,61 @@ gvtm_config config_from_keys(const std::map<std::string, std::string>& k, int pr
 	return c;
 }
 
+gvtm5_config config5_from_keys(const std::map<std::string, std::string>& k)
+{
+	gvtm5_config c{};
+	auto flag = [&](const char* key) {
+		auto it = k.find(key);
+		if (it == k.end()) throw std::runtime_error(std::string("Key '") + key + "' not found.");
+		return it->second == "true" || it->second == "1"; // ConfigurationData::convertString<bool>
+	};
+	c.output_rate = num(k, "output_rate");
+	c.waveform = static_cast<int>(num(k, "waveform"));
+	c.noise_modulation = static_cast<int>(num(k, "noise_modulation"));
+	c.bypass = static_cast<int>(num(k, "bypass"));
+	c.constant_radius_mouth_impedance = flag("constant_radius_mouth_impedance") ? 1 : 0;
+	c.glottal_pulse_tp = num(k, "glottal_pulse_tp");
+	c.glottal_pulse_tn_min = num(k, "glottal_pulse_tn_min");
+	c.glottal_pulse_tn_max = num(k, "glottal_pulse_tn_max");
+	c.breathiness = num(k, "breathiness");
+	c.vocal_tract_length_offset = num(k, "vocal_tract_length_offset");
+	c.vocal_tract_length = num(k, "vocal_tract_length");
+	c.temperature = num(k, "temperature");
+	c.loss_factor = num(k, "loss_factor");
+	c.mix_offset = num(k, "mix_offset");
+	c.global_radius_coef = num(k, "global_radius_coef");
+	c.global_nasal_radius_coef = num(k, "global_nasal_radius_coef");
+	for (int i = 0; i < 6; ++i) c.nasal_radius[i] = num(k, ("nasal_radius_" + std::to_string(i + 2)).c_str());
+	for (int i = 0; i < 8; ++i) c.radius_coef[i] = num(k, ("radius_" + std::to_string(i + 1) + "_coef").c_str());
+	c.glottal_noise_cutoff = num(k, "glottal_noise_cutoff");
+	c.frication_noise_cutoff = num(k, "frication_noise_cutoff");
+	c.frication_factor = num(k, "frication_factor");
+	c.min_glottal_loss = num(k, "min_glottal_loss");
+	c.max_glottal_loss = num(k, "max_glottal_loss");
+	c.glottal_lowpass_cutoff = num(k, "glottal_lowpass_cutoff");
+	if (c.constant_radius_mouth_impedance) c.mouth_impedance_radius = num(k, "mouth_impedance_radius");
+	c.precision = GVTM_PRECISION_F64;
+	return c;
+}
+
 void BatchController::init(const std::map<std::string, std::string>& keys, unsigned control_period_ms, const std::vector<int>& devices, int precision)
 {
 	if (control_period_ms == 0 || control_period_ms > 4) throw std::runtime_error("Invalid control period."); // VTMControlModelConfiguration.cpp:38
 	if (devices.empty()) throw std::runtime_error("no device given");
-	config_ = config_from_keys(keys, precision);
+	const bool model5 = keys.count("model") && static_cast<int>(num(keys, "model")) == 5; // VocalTractModel.cpp:47-48
+	gvtm5_config config5{};
+	if (model5) {
+		config5 = config5_from_keys(keys);
+		config_ = gvtm_config{};
+		config_.output_rate = config5.output_rate;
+	} else {
+		config_ = config_from_keys(keys, precision);
+	}
 	const double control_rate = 1000.0 / control_period_ms;
 	for (int device : devices) {
 		gvtm_plan* plan = nullptr;
-		if (gvtm_plan_create(&config_, control_rate, device, &plan) != GVTM_OK) {
+		const int rc = model5 ? gvtm_plan_create_model5(&config5, control_rate, device, &plan) : gvtm_plan_create(&config_, control_rate, device, &plan);
+		if (rc != GVTM_OK) {
 			const std::string why = gvtm_last_error();
 			for (gvtm_plan* p : plans_) gvtm_plan_destroy(p);
 			plans_.clear();
@@ -144,7 +190,7 @@ double BatchController::internalSampleRate() const
 {
 	gvtm_info info{};
 	gvtm_plan_info(plans_.front(), &info);
-	return info.internal_sample_rate;
+	return info.internal_rate_hz;
 }
 
 std::size_t BatchController::addUtteranceFromStream(std::istream& in)

@@ -21,8 +21,10 @@ std::map<std::string, std::string> read_key_value_file(const std::string& path);
 
 // vtm.txt keys (merged with the variant) -> gvtm_config.  `model` selects the semantics:
 // 0, 2 -> SectionDelay 1; 3 -> SectionDelay 3; 4 -> the 30+18-section tube (VocalTractModel.cpp:40-49);
-// others are refused.
+// 1 -> model 0 in float; 5 is handled by config5_from_keys; others are refused.
 gvtm_config config_from_keys(const std::map<std::string, std::string>& keys, int precision);
+// the keys of a model-5 voice (VocalTractModel5::loadConfiguration, vtm/VocalTractModel5.h:375-421) -> gvtm5_config
+gvtm5_config config5_from_keys(const std::map<std::string, std::string>& keys);
 
 class BatchController {
 public:

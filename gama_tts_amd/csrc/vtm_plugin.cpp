@@ -66,6 +66,54 @@ public:
 	explicit DeviceVocalTractModel(const ConfigurationDataMirror& data)
 	{
 		const KeyReader k(data);
+		const int device = k.has("gpu_device") ? k.integer("gpu_device") : 0;
+		if (k.has("gpu_model") && k.integer("gpu_model") == 5) {
+			// the keys of VocalTractModel5::loadConfiguration (vtm/VocalTractModel5.h:375-421)
+			gvtm5_config c5{};
+			c5.output_rate = k.number("output_rate");
+			c5.waveform = k.integer("waveform");
+			c5.noise_modulation = k.integer("noise_modulation");
+			c5.bypass = k.integer("bypass");
+			const std::string cm = k.text("constant_radius_mouth_impedance", "false");
+			c5.constant_radius_mouth_impedance = (cm == "true" || cm == "1") ? 1 : 0;
+			c5.glottal_pulse_tp = k.number("glottal_pulse_tp");
+			c5.glottal_pulse_tn_min = k.number("glottal_pulse_tn_min");
+			c5.glottal_pulse_tn_max = k.number("glottal_pulse_tn_max");
+			c5.breathiness = k.number("breathiness");
+			c5.vocal_tract_length_offset = k.number("vocal_tract_length_offset");
+			c5.vocal_tract_length = k.number("vocal_tract_length");
+			c5.temperature = k.number("temperature");
+			c5.loss_factor = k.number("loss_factor");
+			c5.mix_offset = k.number("mix_offset");
+			c5.global_radius_coef = k.number("global_radius_coef");
+			c5.global_nasal_radius_coef = k.number("global_nasal_radius_coef");
+			static const char* const nasal5[6] = {"nasal_radius_2", "nasal_radius_3", "nasal_radius_4", "nasal_radius_5", "nasal_radius_6", "nasal_radius_7"};
+			static const char* const coef5[8] = {"radius_1_coef", "radius_2_coef", "radius_3_coef", "radius_4_coef",
+					"radius_5_coef", "radius_6_coef", "radius_7_coef", "radius_8_coef"};
+			for (int i = 0; i < 6; ++i) c5.nasal_radius[i] = k.number(nasal5[i]);
+			for (int i = 0; i < 8; ++i) c5.radius_coef[i] = k.number(coef5[i]);
+			c5.glottal_noise_cutoff = k.number("glottal_noise_cutoff");
+			c5.frication_noise_cutoff = k.number("frication_noise_cutoff");
+			c5.frication_factor = k.number("frication_factor");
+			c5.min_glottal_loss = k.number("min_glottal_loss");
+			c5.max_glottal_loss = k.number("max_glottal_loss");
+			c5.glottal_lowpass_cutoff = k.number("glottal_lowpass_cutoff");
+			if (c5.constant_radius_mouth_impedance) c5.mouth_impedance_radius = k.number("mouth_impedance_radius");
+			c5.precision = GVTM_PRECISION_F64;
+			gvtm_plan* probe = nullptr;
+			if (gvtm_plan_create_model5(&c5, 1000.0, GVTM_DEVICE_NONE, &probe) != GVTM_OK) throw std::runtime_error(gvtm_last_error());
+			gvtm_info info{};
+			gvtm_plan_info(probe, &info);
+			gvtm_plan_destroy(probe);
+			internal_rate_ = info.internal_rate_hz; // not an integer (vtm/VocalTractModel5.h:465)
+			output_rate_ = c5.output_rate;
+			if (gvtm_plan_create_model5(&c5, info.internal_rate_hz, device, &plan_) != GVTM_OK) throw std::runtime_error(gvtm_last_error());
+			gvtm_plan_info(plan_, &info);
+			if (info.control_steps != 1) throw std::runtime_error("internal error: plugin plan must run one step per frame");
+			current_.assign(GVTM_N_PARAM, 0.0f);
+			output_.reserve(1024);
+			return;
+		}
 		gvtm_config c{};
 		c.output_rate = k.number("output_rate");
 		c.waveform = k.integer("waveform");
@@ -95,7 +143,6 @@ public:
 		c.tube_layout = k.has("tube_layout") ? k.integer("tube_layout") : GVTM_TUBE_10_6;
 		const std::string prec = k.text("gpu_precision", "f64");
 		c.precision = prec == "mixed" ? GVTM_PRECISION_MIXED : (prec == "f32" ? GVTM_PRECISION_F32 : GVTM_PRECISION_F64);
-		const int device = k.has("gpu_device") ? k.integer("gpu_device") : 0;
 
 		// The host interpolates the control frames itself (Controller.cpp:294-311) and hands over
 		// one parameter vector per internal step, so the plan runs with one step per "frame":

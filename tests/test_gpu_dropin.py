@@ -153,3 +153,67 @@ def test_batched_cli_shards_across_device_slots(golden, tmp_path):
         outs[tag] = [open(os.path.join(out_dir, "u%d.wav" % n), "rb").read() for n in range(len(files))]
     assert outs["one"] == outs["three"]
     assert len(outs["one"][0]) > 44 and len(outs["one"][4]) > 44
+
+
+@pytest.mark.skipif(oracle.ref_binary() is None, reason="oracle/_ref/ref_vtm (the compiled reference) not present")
+def test_plugin_model5_through_reference_loader(golden, golden5, tmp_path):
+    """`gpu_model = 5` in vtm.txt makes the plugin stand in for reference model 5 (VocalTractModel5<double,1>); the
+    reference's own loader and driver loop see its non-integer internal rate."""
+    keys = oracle.read_config_file(oracle.VOICE5_MALE)
+    keys["gpu_model"] = "5"
+    cfg = str(tmp_path / "vtm5.txt")
+    with open(cfg, "w") as f:
+        for k, v in keys.items():
+            f.write("%s = %s\n" % (k, v))
+    import golden5_cases
+    case = next(c for c in golden5_cases.CASES if c["name"] == "rand5_m5")
+    tr = golden5_cases.track_for(case, golden)
+    out, info = oracle.ref_synthesize(tr, "2000:" + PLUGIN, output_rate=48000, config=cfg, tmpdir=str(tmp_path))
+    ref = golden5["rand5_m5__out"]
+    assert out.size == ref.size == int(info["N"])
+    assert abs(float(info["fs"]) - golden5["manifest"]["rand5_m5"]["fs"]) < 1e-6
+    from test_gpu_model5 import _check
+    _check(out, ref)
+
+
+def test_batched_vtm_cli_model5_voice(golden, tmp_path):
+    """A voice directory whose vtm.txt says `model = 5` (the layout of data/voice/english/5_male): the batched CLI
+    writes what `gama_tts vtm` writes for it."""
+    voice = str(tmp_path / "voice5")
+    keys = oracle.read_config_file(oracle.VOICE5_MALE)
+    os.makedirs(os.path.join(voice, "variant"))
+    variant_keys = ("vocal_tract_length", "glottal_pulse_tp", "glottal_pulse_tn_min", "glottal_pulse_tn_max",
+                    "reference_glottal_pitch", "breathiness", "intonation_factor", "nasal_radius_2", "nasal_radius_3")
+    with open(os.path.join(voice, "_index.txt"), "w") as f:
+        f.write("variant_dir = variant/\nvtm_control_model_file = vtm_control_model.txt\nvtm_file = vtm.txt\n")
+    with open(os.path.join(voice, "vtm.txt"), "w") as f:
+        for k, v in keys.items():
+            if k not in variant_keys:
+                f.write("%s = %s\n" % (k, v))
+    with open(os.path.join(voice, "variant", "male.txt"), "w") as f:
+        for k in variant_keys:
+            f.write("%s = %s\n" % (k, keys[k]))
+    with open(os.path.join(voice, "vtm_control_model.txt"), "w") as f:
+        f.write("control_period = 4\nvariant_name = male\n")
+    out_dir = str(tmp_path / "out5")
+    os.makedirs(out_dir)
+    tracks_ = {"hello": np.asarray(golden["hello_params"]), "short": np.asarray(golden["hello_params"])[:40]}
+    files = []
+    for name, tr in tracks_.items():
+        p = str(tmp_path / (name + "5.txt"))
+        with open(p, "w") as f:
+            for row in tr:
+                f.write(" ".join("%.9g" % v for v in row) + "\n")
+        files.append(p)
+    r = subprocess.run([CLI, voice, out_dir] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cfg = oracle.male5_config(48000.0)
+    for name, tr in tracks_.items():
+        fmt, pcm = _read_wav(os.path.join(out_dir, name + "5.wav"))
+        assert fmt == (16, 1, 1, 48000, 96000, 2, 16)
+        ref, _ = oracle.synthesize5(cfg, tr)
+        assert pcm.size == ref.size
+        scaled = (ref * np.float32(oracle.output_scale(ref))) * np.float32(32767.0)
+        want = (np.sign(scaled) * np.floor(np.abs(scaled) + np.float32(0.5))).astype(np.int32)
+        assert np.abs(pcm.astype(np.int32) - want).max() <= 1
+        assert np.mean(pcm.astype(np.int32) == want) > 0.999
