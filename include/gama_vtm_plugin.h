@@ -30,7 +30,8 @@
  *   - Optional extra keys in vtm.txt: `gpu_device` (int, default 0), `gpu_precision`
  *     ("f64" default = model 0 / 2 / 3 / 4 semantics | "mixed" | "f32" = the float models, i.e. what
  *     `model = 1` selects in the reference), `section_delay` (1..4, default 1: VocalTractModel0 semantics;
- *     3 reproduces model 3), `tube_layout` (0 default; 1 = the 30+18-section tube of model 4).
+ *     3 reproduces model 3), `tube_layout` (0 default; 1 = the 30+18-section tube of model 4),
+ *     `gpu_model` (5 = the voice holds VocalTractModel5's keys and the plugin stands in for reference model 5).
  */
 #ifndef GAMA_VTM_PLUGIN_H_
 #define GAMA_VTM_PLUGIN_H_
