@@ -31,10 +31,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False):
+def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, model5=False):
     """Single-thread CPU throughput (output samples/s) on a bounded sample of the workload."""
     import numpy as np
     import oracle
+    voice = oracle.VOICE5_MALE if model5 else oracle.VOICE_MALE
 
     sample = params[:4]
     kind = None
@@ -52,31 +53,38 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False):
     model = {1: "0", 2: "2:2", 3: "3", 4: "2:4"}[delay]
     if float_model:  # the reference's TFloat = float classes
         model = {1: "1", 2: "2f:2", 3: "2f:3", 4: "2f:4"}[delay]
+    if model5:
+        model = "5"
     if exe_kind:
         kind = "reference"
-        _, info = oracle.ref_synthesize(sample[0], model, output_rate, 250.0, kind=exe_kind, repeat=2)
+        _, info = oracle.ref_synthesize(sample[0], model, output_rate, 250.0, config=voice, kind=exe_kind, repeat=2)
         per_rep = float(info["sec"]) / 2
         repeat = max(1, int(budget_s / max(per_rep, 1e-6) / len(sample)))
         total_samples = 0
         total_sec = 0.0
         for tr in sample:
-            _, info = oracle.ref_synthesize(tr, model, output_rate, 250.0, kind=exe_kind, repeat=repeat)
+            _, info = oracle.ref_synthesize(tr, model, output_rate, 250.0, config=voice, kind=exe_kind, repeat=repeat)
             total_samples += int(info["N"]) * repeat
             total_sec += float(info["sec"])
         desc = "%d utterances x %d repeats of %d frames through oracle/_ref/ref_vtm_%s (model %s)" % (
             len(sample), repeat, sample.shape[1], exe_kind, model)
     else:
         kind = "port"
-        cfg = oracle.male_config(output_rate, delay, float_model=int(float_model))
+        if model5:
+            cfg5 = oracle.male5_config(output_rate)
+            synth = lambda tr: oracle.synthesize5(cfg5, tr)[0]  # noqa: E731
+        else:
+            cfg = oracle.male_config(output_rate, delay, float_model=int(float_model))
+            synth = lambda tr: oracle.synthesize(cfg, tr)  # noqa: E731
         t0 = time.perf_counter()
-        out = oracle.synthesize(cfg, sample[0])
+        out = synth(sample[0])
         per = time.perf_counter() - t0
         repeat = max(1, int(budget_s / max(per, 1e-6) / len(sample)))
         total_samples = 0
         t0 = time.perf_counter()
         for tr in sample:
             for _ in range(repeat):
-                total_samples += oracle.synthesize(cfg, tr).size
+                total_samples += synth(tr).size
         total_sec = time.perf_counter() - t0
         desc = "%d utterances x %d repeats of %d frames through oracle/vtm_oracle.c" % (len(sample), repeat, sample.shape[1])
     return {"value": total_samples / total_sec, "unit": "samples/s", "cores": 1, "kind": kind, "sample": desc}
@@ -94,7 +102,10 @@ def main():
                     help="f32 (default; BASELINE configs[1] is 'VTM0 fp32') = VocalTractModel0<float>, reference model 1, "
                          "output bit-identical to it; f64 = VocalTractModel0<double>, model 0 (reported under 'extras'); "
                          "mixed = fp64 with an fp32 resampler")
-    ap.add_argument("--output-rate", type=float, default=44100.0)
+    ap.add_argument("--output-rate", type=float, default=None, help="default 44100 (48000 with --model 5, the 5_male voice's own rate)")
+    ap.add_argument("--model", type=int, choices=[0, 5], default=0,
+                    help="0: the VocalTractModel0/2 path (default, BASELINE configs); 5: reference model 5 (VocalTractModel5<double,1>, "
+                         "its own kernel; fp64, --delay / --precision ignored)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (other precision, batch 4096)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
@@ -128,16 +139,24 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    voice = os.path.join(ROOT, "tests", "golden", "voice_male.txt")
+    model5 = args.model == 5
+    if args.output_rate is None:
+        args.output_rate = 48000.0 if model5 else 44100.0
+    if model5:
+        args.precision, args.delay = "f64", 1
+    voice = os.path.join(ROOT, "tests", "golden", "voice5_male.txt" if model5 else "voice_male.txt")
     cfgd = g.read_config_file(voice)
     prec = {"f64": capi.PRECISION_F64, "mixed": capi.PRECISION_MIXED, "f32": capi.PRECISION_F32}[args.precision]
-    plan = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay, prec), 250.0, local_rank)
+    if model5:
+        plan = g.Plan(g.config5_from_dict(cfgd, args.output_rate), 250.0, local_rank)
+    else:
+        plan = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay, prec), 250.0, local_rank)
     n_out = plan.output_count(args.frames)
 
     # synthetic tracks: SURVEY.md 8(d) config-2 generator; a pool of distinct tracks is tiled
     # over the batch so that host-side generation stays cheap for big batches
     pool = min(args.batch, 256)
-    host_pool = tracks.random_tracks(pool, args.frames, seed0=1000 + 100000 * rank)
+    host_pool = tracks.random_tracks(pool, args.frames, seed0=1000 + 100000 * rank, consonant_heavy=model5)
     reps = (args.batch + pool - 1) // pool
     d_pool = torch.from_numpy(host_pool).to(dev)
     d_params = d_pool.repeat((reps, 1, 1))[: args.batch].contiguous()
@@ -180,14 +199,14 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            key = "batch%d_frames%d_delay%d_%s" % (args.batch, args.frames, args.delay, args.precision)
+            key = "batch%d_frames%d_delay%d_%s%s" % (args.batch, args.frames, args.delay, args.precision, "_model5" if model5 else "")
             traffic = json.load(f).get(key, {}).get("bytes")
     except (OSError, ValueError):
         pass
 
     if rank == 0:
         line = {
-            "metric": "audio samples/sec (whole node), batched VTM @44.1kHz",
+            "metric": "audio samples/sec (whole node), batched VTM @%s" % ("48kHz" if model5 and args.output_rate == 48000.0 else "44.1kHz"),
             "value": value,
             "unit": "samples/s",
             "n_gpus": world,
@@ -201,7 +220,10 @@ def main():
             "data": "synthetic",
             "real_time_factor": value / args.output_rate,
             "config": {
-                "workload": "batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel%s<%s> "
+                "workload": ("batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel5<double> (reference "
+                             "model 5), 5_male voice, %.0f Hz out" % (args.batch, args.frames, args.frames * 0.004, args.output_rate))
+                            if model5 else
+                            "batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel%s<%s> "
                             "semantics (SectionDelay %d), male voice, %.0f Hz out" % (
                                 args.batch, args.frames, args.frames * 0.004, "0" if args.delay == 1 else "2",
                                 "float" if args.precision == "f32" else "double", args.delay, args.output_rate),
@@ -218,13 +240,14 @@ def main():
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": traffic,
-                "kernel": "gvtm::v2::vtm_synth_kernel" if os.environ.get("GVTM_KERNEL", "2") != "1" else "gvtm::v1::vtm_synth_kernel",
+                "kernel": "gvtm::m5::vtm5_synth_kernel" if model5 else (
+                    "gvtm::v2::vtm_synth_kernel" if os.environ.get("GVTM_KERNEL", "2") != "1" else "gvtm::v1::vtm_synth_kernel"),
                 "kernel_ms": kernel_ms,
                 "launches_timed": launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and not model5:
             # the same kernel in the other arithmetic (BASELINE configs[1] names fp32, configs[3] an fp32/fp64
             # sweep) and at the batch BASELINE's target is quoted on; short runs, reported beside the headline
             def extra(precision, batch):
@@ -253,7 +276,7 @@ def main():
             other = "f32" if args.precision != "f32" else "f64"
             line["extras"] = [extra(other, args.batch), extra(args.precision, 4096), extra(other, 4096)]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=args.precision == "f32")
+            line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=args.precision == "f32", model5=model5)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -19,7 +19,7 @@ def one(pattern):
     return hits[0] if hits else None
 
 
-for name in ("bench.json", "bench_f64.json", "bench_batches.jsonl", "bench_config4.jsonl", "bench_aux.json", "bench_m5.json",
+for name in ("bench.json", "bench_f64.json", "bench_batches.jsonl", "bench_config4.jsonl", "bench_aux.json", "bench_m5.json", "bench_model5.json",
              "config3_parity.json", "model5_parity.json", "role_cycles_f64_u1.txt", "role_cycles_f32_u1.txt",
              "role_cycles_f32_u4.txt", "role_cycles_m5.txt"):
     p = os.path.join(src, "%s_%s" % (tag, name))
@@ -32,13 +32,13 @@ for p in ("f32", "f64", "m5"):
 traffic = {"_comment": "HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB); gfx950 "
            "correction per MI355X_MICROARCH.md: FETCH_SIZE x2 for reads, WRITE_SIZE exact. bench.py reports these bytes as "
            "roofline.traffic for the matching workload."}
-for p in ("f64", "f32"):
+for p in ("f64", "f32", "m5"):
     vals, kernel, srcs = {}, None, []
     for counter, short in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         cc = one("%s_%s_%s/*/*_counter_collection.csv" % (tag, short, p))
         if not cc:
             continue
-        rows = [r for r in csv.DictReader(open(cc)) if "vtm_synth_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        rows = [r for r in csv.DictReader(open(cc)) if "synth_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
         out = os.path.join(dst, "%s_pmc_%s_size_%s.csv" % (tag, short, p))
         with open(out, "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
@@ -48,7 +48,7 @@ for p in ("f64", "f32"):
         kernel = rows[0]["Kernel_Name"]
         srcs.append("profiles/" + os.path.basename(out))
     if len(vals) == 2:
-        traffic["batch256_frames500_delay1_" + p] = {"fetch_size_kib": vals["fetch"], "write_size_kib": vals["write"],
+        traffic["batch256_frames500_delay1_" + ("f64_model5" if p == "m5" else p)] = {"fetch_size_kib": vals["fetch"], "write_size_kib": vals["write"],
                                                      "bytes": vals["fetch"] * 1024 * 2 + vals["write"] * 1024, "kernel": kernel, "source": srcs}
 if len(traffic) > 1:
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
