@@ -107,3 +107,20 @@ def test_rejects_what_the_reference_rejects():
         g.Plan(g.config5_from_dict(dict(d, glottal_pulse_tn_min="30.0")), 250.0, 0)
     with pytest.raises(g.GvtmError):  # the factory only offers VocalTractModel5<double,1>
         g.Plan(g.config5_from_dict(d, precision=capi.PRECISION_F32), 250.0, 0)
+
+
+def test_long_utterance_next_to_short_ones():
+    # BASELINE's long form: 7500 frames (30 s, 1.8 M internal steps, the ring and the 16.16 time register wrap many times),
+    # in one launch with a one-frame and an empty utterance
+    long_tr = tracks.random_track(7500, 11, True)
+    params = np.zeros((3, 7500, 16), np.float32)
+    params[0] = long_tr
+    params[1, :1] = long_tr[:1]
+    plan = _plan()
+    audio, counts, maxabs = plan.synthesize_host(params, frame_counts=[7500, 1, 0])
+    cfg = oracle.male5_config(48000.0)
+    for b, f in enumerate((7500, 1, 0)):
+        ref, _ = oracle.synthesize5(cfg, params[b, :f])
+        assert counts[b] == ref.size
+        _check(audio[b, : ref.size], ref)
+        assert maxabs[b] == np.abs(audio[b, : ref.size]).max()
