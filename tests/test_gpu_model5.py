@@ -124,3 +124,29 @@ def test_long_utterance_next_to_short_ones():
         assert counts[b] == ref.size
         _check(audio[b, : ref.size], ref)
         assert maxabs[b] == np.abs(audio[b, : ref.size]).max()
+
+
+def test_full_batch_on_the_device_by_tiling():
+    """4096 utterances x 500 frames resident in HBM: a pool of 64 tracks tiled 64 times, every utterance bit-identical
+    to its pool twin wherever it sits in the launch; two pool members against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    batch, frames, pool_n = 4096, 500, 64
+    pool = tracks.random_tracks(pool_n, frames, seed0=515100, consonant_heavy=True)
+    plan = _plan()
+    n = plan.output_count(frames)
+    d_params = torch.from_numpy(pool).to(dev).repeat((batch // pool_n, 1, 1)).contiguous()
+    d_audio = torch.empty((batch, n), dtype=torch.float32, device=dev)
+    d_counts = torch.zeros(batch, dtype=torch.int64, device=dev)
+    d_max = torch.zeros(batch, dtype=torch.float32, device=dev)
+    plan.synthesize_device(d_params, batch, frames, d_audio, n, None, d_counts, d_max, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool((d_counts == n).all())
+    tiles = d_audio.view(batch // pool_n, pool_n, n)
+    for t in range(1, batch // pool_n):
+        assert torch.equal(tiles[t], tiles[0]), t
+    assert torch.equal(d_max[:pool_n], tiles[0].abs().amax(dim=1))
+    cfg = oracle.male5_config(48000.0)
+    for b in (5, 60):
+        ref, _ = oracle.synthesize5(cfg, pool[b])
+        _check(tiles[33, b].cpu().numpy(), ref)
