@@ -150,3 +150,17 @@ def test_full_batch_on_the_device_by_tiling():
     for b in (5, 60):
         ref, _ = oracle.synthesize5(cfg, pool[b])
         _check(tiles[33, b].cpu().numpy(), ref)
+
+
+def test_special_case_frames():
+    """tracks.edge_track (volumes 0 / 60 dB, frication at the first / last section incl. the dropped right share, radii
+    at the floor, velum 0, pitch and band-pass extremes), alone and inside a batch."""
+    tr = tracks.edge_track(48)
+    ref, _ = oracle.synthesize5(oracle.male5_config(48000.0), tr)
+    plan = _plan()
+    batch = np.stack([tr, tracks.random_track(48, 3, True), tr])
+    for params in (tr[None], batch):
+        audio, counts, _ = plan.synthesize_host(params)
+        assert counts[0] == ref.size and np.isfinite(audio).all()
+        _check(audio[0, : ref.size], ref)
+    assert np.array_equal(audio[2], audio[0])

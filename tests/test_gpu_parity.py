@@ -223,3 +223,16 @@ def test_thirty_section_tube_batch_against_oracle():
         ref = oracle.synthesize(cfg, params[b, :f]) if f else np.zeros(oracle.output_count(cfg, 0), np.float32)
         assert counts[b] == ref.size
         assert _within(audio[b, : ref.size], ref, TOL_F64), _peak_err(audio[b, : ref.size], ref)
+
+
+@pytest.mark.parametrize("delay,layout", [(1, 0), (3, 0), (1, 1)])
+def test_special_case_frames(delay, layout):
+    """tracks.edge_track: volumes 0 / 60 dB, frication at the first / last section, radii at the floor, velum 0, pitch and
+    band-pass extremes — fp64 path against the double oracle."""
+    tr = tracks.edge_track(48)
+    plan = _plan(delay=delay, layout=layout)
+    ref = oracle.synthesize(oracle.male_config(44100.0, delay, layout), tr)
+    audio, counts, _ = plan.synthesize_host(np.stack([tr, tracks.random_track(48, 3, True), tr]))
+    assert counts[0] == ref.size and np.isfinite(audio).all()
+    assert _within(audio[0, : ref.size], ref, TOL_F64), _peak_err(audio[0, : ref.size], ref)
+    assert np.array_equal(audio[2], audio[0])

@@ -60,3 +60,27 @@ def random_track(frames, seed, consonant_heavy=False):
 
 def random_tracks(batch, frames, seed0=1000, consonant_heavy=False):
     return np.stack([random_track(frames, seed0 + b, consonant_heavy) for b in range(batch)])
+
+
+def edge_track(frames=48, seed=0):
+    """Frames that sit ON the special cases of the per-step conversions: volumes 0 / 60 dB (Util::amplitude60dB's two
+    shortcuts), frication position 0 and 7 (first / last injection section, the dropped right share), radii at and below
+    the 0.01 floor, velum 0 (nasal junction coefficient -1), pitch at both ends, bandwidth / centre frequency extremes;
+    held for two frames each so that the interpolation passes THROUGH the values as well."""
+    base = const_track(1)[0]
+    rows = []
+    specials = [
+        {1: 0.0}, {1: 60.0}, {2: 60.0}, {2: 0.0}, {3: 60.0, 4: 0.0}, {3: 60.0, 4: 7.0}, {3: 30.0, 4: 6.999}, {3: 30.0, 4: 3.5},
+        {0: -24.0}, {0: 24.0}, {5: 100.0, 6: 250.0, 3: 40.0}, {5: 5500.0, 6: 4500.0, 3: 40.0},
+        {7: 0.0, 8: 0.005, 9: 0.01}, {14: 0.0}, {14: 3.0, 13: 0.0}, {15: 0.0}, {15: 1.5, 10: 0.1}, {10: 3.0, 11: 0.1},
+    ]
+    for sp in specials:
+        r = base.copy()
+        r[3] = 0.0
+        for k, v in sp.items():
+            r[k] = v
+        rows += [r, r]
+    tr = np.array(rows, dtype=np.float32)
+    if frames > tr.shape[0]:
+        tr = np.concatenate([tr, random_track(frames - tr.shape[0], 9000 + seed, True)])
+    return np.ascontiguousarray(tr[:frames], dtype=np.float32)
