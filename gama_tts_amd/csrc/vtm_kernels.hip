@@ -112,17 +112,33 @@ struct V2Shape {
 	static constexpr int XR = (2 * C + 4 * kMaxPad <= 512) ? 512 : 1024;
 };
 
+// helper wavefronts of the 48-section tube's workgroups: U tube wavefronts + 4 other serial ones + helpers = 12
+// (three wavefronts per SIMD: 168 registers each)
+#ifndef GVTM_TUNE_WIDE_NH2
+#define GVTM_TUNE_WIDE_NH2 6
+#endif
+#ifndef GVTM_TUNE_WIDE_NH4
+#define GVTM_TUNE_WIDE_NH4 4
+#endif
+template <int U>
+constexpr int wide_helpers()
+{
+	return U == 1 ? GVTM_TUNE_NH_SINGLE : (U == 2 ? GVTM_TUNE_WIDE_NH2 : GVTM_TUNE_WIDE_NH4);
+}
+
 template <typename CT, typename ST, int D, int U, int LAYOUT = 0>
 static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
 	using S = V2Shape<CT, ST, U, D>;
-	auto fn = v2::vtm_synth_kernel<CT, ST, D, S::U, S::C, S::NH, S::XR, LAYOUT>;
+	constexpr int NH = LAYOUT == 1 ? wide_helpers<U>() : S::NH;
+	constexpr int kWaves = v2::serial_waves<U, LAYOUT>() + NH;
+	auto fn = v2::vtm_synth_kernel<CT, ST, D, S::U, S::C, NH, S::XR, LAYOUT>;
 	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C, S::XR>();
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
 	if (e != hipSuccess) return e;
 	const unsigned groups = static_cast<unsigned>((batch + S::U - 1) / S::U);
-	hipLaunchKernelGGL(fn, dim3(groups), dim3(S::kWaves * 64), lds, stream, args);
+	hipLaunchKernelGGL(fn, dim3(groups), dim3(kWaves * 64), lds, stream, args);
 	return hipGetLastError();
 }
 
@@ -177,9 +193,11 @@ template <typename CT, typename ST, int U>
 static hipError_t launch_v2_d(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
 	if (args.k.layout == 1) {
-		// VocalTractModel4: 48 section lanes = one utterance per tube wavefront, SectionDelay 1 only
+		// VocalTractModel4: 48 section lanes = one utterance per tube wavefront (up to four of them per
+		// workgroup), SectionDelay 1 only
 		if (args.k.section_delay != 1) return hipErrorInvalidValue;
-		return launch_v2<CT, ST, 1, 1, 1>(args, batch, stream);
+		if constexpr (U >= 4) return launch_v2<CT, ST, 1, 4, 1>(args, batch, stream);
+		else return launch_v2<CT, ST, 1, U, 1>(args, batch, stream);
 	}
 	switch (args.k.section_delay) {
 	case 1: return launch_v2<CT, ST, 1, U>(args, batch, stream);
