@@ -85,3 +85,37 @@ def test_events_to_audio_on_the_device(golden_tracks):
         assert d_n[b].item() == ref.size
         from test_gpu_parity import _within, _peak_err
         assert _within(audio[b, : ref.size], ref, 1e-9), (b, _peak_err(audio[b, : ref.size], ref))
+
+
+def test_events_to_audio_on_the_device_model5(golden_tracks):
+    """The same chain into reference model 5 (the event list and its frames do not depend on the vocal-tract model):
+    frames made on the device feed the model-5 kernel without leaving HBM."""
+    import torch
+    from test_gpu_model5 import _check
+    names = ["question", "hello", "count"]
+    cfgv, _, _ = event_lists.load_golden(golden_tracks, "hello", 0)
+    tables = [event_lists.load_golden(golden_tracks, n, 0)[1] for n in names]
+    want_frames = [oracle.tracks_generate(oracle.track_config(cfgv), t)[0] for t in tables]
+    max_frames = max(f.shape[0] for f in want_frames)
+    dev = torch.device("cuda:0")
+    evs = [capi.events_from_table(t) for t in tables]
+    offsets = np.zeros(len(evs) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(e) for e in evs])
+    d_events = torch.from_numpy(np.concatenate(evs).view(np.uint8)).to(dev)
+    d_offsets = torch.from_numpy(offsets).to(dev)
+    d_params = torch.zeros((len(evs), max_frames, 16), dtype=torch.float32, device=dev)
+    d_counts = torch.zeros(len(evs), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.generate_tracks_device(_product_config(cfgv), d_events, d_offsets, len(evs), max_frames, d_params, d_counts, None, stream)
+    plan = g.Plan(g.config5_from_dict(g.read_config_file(oracle.VOICE5_MALE)), 250.0, 0)
+    n_out = plan.output_count(max_frames)
+    d_audio = torch.zeros((len(evs), n_out), dtype=torch.float32, device=dev)
+    d_n = torch.zeros(len(evs), dtype=torch.int64, device=dev)
+    plan.synthesize_device(d_params, len(evs), max_frames, d_audio, n_out, d_counts, d_n, None, stream)
+    torch.cuda.synchronize()
+    audio = d_audio.cpu().numpy()
+    cfg = oracle.male5_config(48000.0)
+    for b, frames in enumerate(want_frames):
+        ref, _ = oracle.synthesize5(cfg, frames)
+        assert d_n[b].item() == ref.size
+        _check(audio[b, : ref.size], ref)
