@@ -489,6 +489,9 @@ std::string design_plan5(const gvtm5_config& c, double control_rate, Design& out
 		err << "output_rate / internal rate = " << ratio << " is below the supported down-sampling range";
 		return err.str();
 	}
+	// the model 5 kernel parks converted samples in a 512-entry ring until the difference filter has emitted them in
+	// aligned blocks: two chunks of 60 steps must fit beside the held-back block
+	if (ratio > 3.0) return "output_rate above 3x the internal rate is not supported by the model 5 path";
 	design_src_filter<double>(out.src_h, out.src_dh);
 	out.fir.clear();
 	out.wavetable.clear();

@@ -88,15 +88,19 @@ def test_batch_of_identical_tracks_is_identical():
     assert (audio == audio[0]).all()
 
 
-def test_upsampling_branch():
-    # 96 kHz output is above the 60.4 kHz internal rate: the resampler's other branch (SampleRateConverter.h:320-360)
+@pytest.mark.parametrize("rate", [96000.0, 176400.0])
+def test_upsampling_branch(rate):
+    # an output rate above the 60.4 kHz internal rate: the resampler's other branch (SampleRateConverter.h:320-360);
+    # 176.4 kHz is close to the largest ratio the sink's ring takes (3x, refused above)
     tr = tracks.random_track(30, 5, True)
-    plan = _plan(rate=96000.0)
+    plan = _plan(rate=rate)
     assert plan.info.upsampling == 1
     audio, counts, _ = plan.synthesize_host(tr[None])
-    ref, _ = oracle.synthesize5(oracle.male5_config(96000.0), tr)
+    ref, _ = oracle.synthesize5(oracle.male5_config(rate), tr)
     assert counts[0] == ref.size
     _check(audio[0, : ref.size], ref)
+    with pytest.raises(g.GvtmError):
+        _plan(rate=192000.0)
 
 
 def test_rejects_what_the_reference_rejects():
