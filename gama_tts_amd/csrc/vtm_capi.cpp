@@ -488,7 +488,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
 	}
 	const bool model5 = plan->design.model5;
-	const int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows);
+	const int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows, plan->design.k.section_delay);
 	if ((model5 ? gvtm::synth5_lds_bytes() : gvtm::synth_lds_bytes(plan->precision, plan->generation, rows)) > 160 * 1024) {
 		return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
 	}

@@ -148,7 +148,7 @@ hipError_t launch_dpp_selftest(int* d_out, hipStream_t stream)
 	return hipGetLastError();
 }
 
-int synth_rows(int precision, size_t batch, int requested)
+int synth_rows(int precision, size_t batch, int requested, int section_delay)
 {
 	// utterances per workgroup = DPP rows used by the serial wavefronts.  One row keeps the most
 	// workgroups in flight (best latency for small batches); more rows amortise the serial
@@ -161,6 +161,8 @@ int synth_rows(int precision, size_t batch, int requested)
 		// fp64: four rows fit since the resampler table lost its delta half, but measured no faster than two
 		// (9.2 vs 8.9 ms on batch 1024: the fp64 serial chains spill at 12 wavefronts per workgroup)
 		if (precision == GVTM_PRECISION_F64 && rows > 2) rows = 2;
+		// mixed with SectionDelay 3 or 4 (deeper fp64 delay lines per lane): measured 3.36 vs 2.63 and 2.07 vs 1.65 G samples/s
+		if (precision == GVTM_PRECISION_MIXED && section_delay >= 3 && rows > 2) rows = 2;
 	}
 	return rows > max_rows ? max_rows : rows;
 }

@@ -48,7 +48,7 @@ struct NormalizeArgs {
 // rows: utterances per workgroup for generation 2 (1, 2 or 4); synth_rows() picks it from the
 // batch size unless `requested` names one
 // precision: gvtm_precision (GVTM_PRECISION_F32 runs on generation 2 only)
-int synth_rows(int precision, size_t batch, int requested);
+int synth_rows(int precision, size_t batch, int requested, int section_delay = 1);
 size_t synth_lds_bytes(int precision, int generation, int rows);
 hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int generation, int rows, hipStream_t stream);
 // reference model 5 (VocalTractModel5<double,1>): one utterance per workgroup, fp64
