@@ -82,19 +82,22 @@ struct V2Shape {
 	static constexpr int U = U_;
 	// Chunk length C: a multiple of 4 (scan blocks) and of the tube unroll (2 for SectionDelay 1, D for
 	// even D, 6 for 3), i.e. of 12.
-	//   U = 1: the tick time is the tube wavefront's, whatever C (60 = one helper pass per stage, and no
-	//          power-of-two LDS strides, measured 4 % faster than 64).
+	//   U = 1: the tick time is the tube wavefront's plus what a tick costs besides (barrier, stage prologues): measured
+	//          on batch 256 in float, C = 60 / 96 / 120 / 144 / 168 / 192 -> 3.73 / 3.58 / 3.53 / 3.48 / 3.52 / 3.59 ms (108 and
+	//          180, whose last 64-item helper pass is half empty: 3.73 / 3.70); mixed 60 / 96 / 120 -> 4.19 / 4.04 / 4.15;
+	//          fp64 60 / 72 / 84 -> 4.14 / 4.65 / 4.07 (LDS ends there).  No power-of-two lengths (LDS strides).
 	//   U > 1: every tick has fixed costs (barrier, stage prologues, ticket traffic, partly filled 64-item
 	//          passes), so the longest chunk LDS allows wins: measured on batch 4096 in float, C = 24 / 36 / 48
 	//          -> 24.8 / 21.6 / 18.4 ms; batch 512, C = 24 / 48 / 96 -> 4.71 / 4.64 / 4.38 ms.
-	// LDS per workgroup (KB): float 1x60 65, 2x96 143, 4x48 144; mixed 1x60 94, 2x48 131, 4x24 138;
-	// fp64 1x60 122, 2x48 135 and 4x24 146 (resampler table without its delta half).
+	// LDS per workgroup (KB): float 1x144 118, 2x96 143, 4x48 144; mixed 1x96 132, 2x48 131, 4x24 138;
+	// fp64 1x84 148, 2x48 135 and 4x24 146 (resampler table without its delta half).
 	static constexpr bool kAllFloat = sizeof(CT) == 4;
 	static constexpr bool kMixed = sizeof(CT) == 8 && sizeof(ST) == 4;
 #ifdef GVTM_TUNE_C1
 	static constexpr int C = (U_ == 1) ? GVTM_TUNE_C1 : (U_ == 2 ? GVTM_TUNE_C2 : GVTM_TUNE_C4);
 #else
-	static constexpr int C = (U_ == 1) ? 60 : (U_ == 2 ? (kAllFloat ? 96 : 48) : (U_ == 8 ? 24 : (kAllFloat ? 48 : 24)));
+	static constexpr int C = (U_ == 1) ? (kAllFloat ? 144 : (kMixed ? 96 : 84))
+	                                   : (U_ == 2 ? (kAllFloat ? 96 : 48) : (U_ == 8 ? 24 : (kAllFloat ? 48 : 24)));
 #endif
 #ifndef GVTM_TUNE_NH_MULTI
 #define GVTM_TUNE_NH_MULTI 7
