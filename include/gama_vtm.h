@@ -181,7 +181,10 @@ int gvtm_device_count(void);
 int gvtm_plan_create(const gvtm_config* config, double control_rate, int device, gvtm_plan** plan_out);
 /* The same for reference model 5 (VocalTractModel5 constructor: loadConfiguration + initializeSynthesizer,
  * vtm/VocalTractModel5.h:375-421, :455-521).  The plan is used with the same synthesis entry points;
- * gvtm_plan_table() serves the resampler tables only. */
+ * gvtm_plan_table() serves the resampler tables only.  Refused (GVTM_ERR_INVALID_ARGUMENT), as the reference's constructors
+ * refuse them: an internal rate below 50 kHz (vocal tract longer than ~21 cm, PoleZeroRadiationImpedance.h:116-119),
+ * glottal pulse timings outside RosenbergBGlottalSource's checks, Butterworth cutoffs outside 1 Hz .. 0.48 of the internal
+ * rate; and, a limit of this implementation, an output rate above 3x the internal rate. */
 int gvtm_plan_create_model5(const gvtm5_config* config, double control_rate, int device, gvtm_plan** plan_out);
 void gvtm_plan_destroy(gvtm_plan* plan);
 int gvtm_plan_info(const gvtm_plan* plan, gvtm_info* info_out);
