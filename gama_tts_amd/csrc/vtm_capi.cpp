@@ -3,6 +3,7 @@
 // plugin convention: construct returns nullptr, VocalTractModelPlugin.cpp:87-90).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -79,6 +80,9 @@ struct gvtm_plan {
 	unsigned long long* phase_cycles = nullptr; // device pointer, see gvtm_debug_set_phase_cycles
 	std::vector<EventPair> pending;
 	std::vector<EventPair> pool;
+	// host-buffer entry on large batches: kernels on one stream, copies back on another (created on first use)
+	hipStream_t compute_stream = nullptr, copy_stream = nullptr;
+	std::vector<hipEvent_t> slice_done;
 };
 
 namespace {
@@ -110,6 +114,9 @@ void free_plan(gvtm_plan* p)
 	p->s_audio.release();
 	p->s_counts.release();
 	p->s_maxabs.release();
+	if (p->compute_stream) (void) hipStreamDestroy(p->compute_stream);
+	if (p->copy_stream) (void) hipStreamDestroy(p->copy_stream);
+	for (hipEvent_t ev : p->slice_done) (void) hipEventDestroy(ev);
 	for (auto& ev : p->pending) { (void) hipEventDestroy(ev.start); (void) hipEventDestroy(ev.stop); }
 	for (auto& ev : p->pool) { (void) hipEventDestroy(ev.start); (void) hipEventDestroy(ev.stop); }
 	delete p;
@@ -567,17 +574,59 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 	if (frame_counts && (e = hipMemcpy(plan->s_frames.ptr, frame_counts, sizeof(int32_t) * batch, hipMemcpyHostToDevice)) != hipSuccess) {
 		return fail_hip(e, "H2D frame_counts");
 	}
-	const int rc = gvtm_synthesize_batch_device(plan, static_cast<const float*>(plan->s_params.ptr),
-			frame_counts ? static_cast<const int32_t*>(plan->s_frames.ptr) : nullptr, batch, max_frames,
-			static_cast<float*>(plan->s_audio.ptr), audio_stride, static_cast<int64_t*>(plan->s_counts.ptr),
-			static_cast<float*>(plan->s_maxabs.ptr), nullptr);
-	if (rc != GVTM_OK) return rc;
-	if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
-	if ((e = hipMemcpy(audio, plan->s_audio.ptr, abytes, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H audio");
-	if (out_counts && (e = hipMemcpy(out_counts, plan->s_counts.ptr, sizeof(int64_t) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
+	// Large batches go in slices: the kernels of all slices are queued on one stream, and each slice's samples are
+	// copied back on another stream as soon as its kernel has finished, while the following slices still compute
+	// (1.4 GB come back for 4096 x 2 s: the copy takes longer than the kernels).  A slice keeps every compute unit
+	// busy with the shape the whole batch would have used (1024 utterances = 256 workgroups of four).
+	constexpr size_t kSlice = 1024;
+	float* const d_params = static_cast<float*>(plan->s_params.ptr);
+	const int32_t* const d_frames = frame_counts ? static_cast<const int32_t*>(plan->s_frames.ptr) : nullptr;
+	float* const d_audio = static_cast<float*>(plan->s_audio.ptr);
+	int64_t* const d_counts = static_cast<int64_t*>(plan->s_counts.ptr);
+	float* const d_maxabs = static_cast<float*>(plan->s_maxabs.ptr);
+	if (batch >= 2 * kSlice) {
+		if (!plan->compute_stream && (e = hipStreamCreateWithFlags(&plan->compute_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
+		if (!plan->copy_stream && (e = hipStreamCreateWithFlags(&plan->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
+		const size_t n_slices = (batch + kSlice - 1) / kSlice;
+		while (plan->slice_done.size() < n_slices) {
+			hipEvent_t ev = nullptr;
+			if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail_hip(e, "hipEventCreate");
+			plan->slice_done.push_back(ev);
+		}
+		const int saved_rows = plan->rows;
+		if (plan->rows == 0) plan->rows = gvtm::synth_rows(plan->precision, batch, 0, plan->design.k.section_delay); // the whole batch's shape
+		int rc = GVTM_OK;
+		for (size_t i = 0; i < n_slices && rc == GVTM_OK; ++i) {
+			const size_t lo = i * kSlice, n = std::min(kSlice, batch - lo);
+			rc = gvtm_synthesize_batch_device(plan, d_params + lo * max_frames * GVTM_N_PARAM, d_frames ? d_frames + lo : nullptr, n, max_frames,
+					d_audio + lo * audio_stride, audio_stride, d_counts + lo, d_maxabs + lo, plan->compute_stream);
+			if (rc == GVTM_OK && (e = hipEventRecord(plan->slice_done[i], plan->compute_stream)) != hipSuccess) rc = fail_hip(e, "hipEventRecord");
+		}
+		plan->rows = saved_rows;
+		if (rc != GVTM_OK) {
+			(void) hipStreamSynchronize(plan->compute_stream);
+			return rc;
+		}
+		for (size_t i = 0; i < n_slices; ++i) {
+			const size_t lo = i * kSlice, n = std::min(kSlice, batch - lo);
+			if ((e = hipStreamWaitEvent(plan->copy_stream, plan->slice_done[i], 0)) != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
+			if ((e = hipMemcpyAsync(audio + lo * audio_stride, d_audio + lo * audio_stride, sizeof(float) * n * audio_stride, hipMemcpyDeviceToHost,
+					plan->copy_stream)) != hipSuccess) {
+				return fail_hip(e, "D2H audio");
+			}
+		}
+		if ((e = hipStreamSynchronize(plan->copy_stream)) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution / D2H audio");
+		if ((e = hipStreamSynchronize(plan->compute_stream)) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
+	} else {
+		const int rc = gvtm_synthesize_batch_device(plan, d_params, d_frames, batch, max_frames, d_audio, audio_stride, d_counts, d_maxabs, nullptr);
+		if (rc != GVTM_OK) return rc;
+		if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
+		if ((e = hipMemcpy(audio, d_audio, abytes, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H audio");
+	}
+	if (out_counts && (e = hipMemcpy(out_counts, d_counts, sizeof(int64_t) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
 		return fail_hip(e, "D2H counts");
 	}
-	if (maxabs && (e = hipMemcpy(maxabs, plan->s_maxabs.ptr, sizeof(float) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
+	if (maxabs && (e = hipMemcpy(maxabs, d_maxabs, sizeof(float) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
 		return fail_hip(e, "D2H maxabs");
 	}
 	return GVTM_OK;

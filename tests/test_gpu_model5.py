@@ -168,3 +168,20 @@ def test_special_case_frames():
         assert counts[0] == ref.size and np.isfinite(audio).all()
         _check(audio[0, : ref.size], ref)
     assert np.array_equal(audio[2], audio[0])
+
+
+def test_host_entry_slices_large_batches():
+    batch, frames = 2100, 6
+    pool = tracks.random_tracks(50, frames, seed0=717000, consonant_heavy=True)
+    params = np.ascontiguousarray(np.tile(pool, (batch // 50, 1, 1)))
+    fc = (np.arange(batch) % (frames + 1)).astype(np.int32)
+    plan = _plan()
+    audio, counts, _ = plan.synthesize_host(params, fc)
+    cfg = oracle.male5_config(48000.0)
+    for b in (0, 1023, 1024, 2047, 2048, batch - 1):
+        ref, _ = oracle.synthesize5(cfg, params[b, : fc[b]])
+        assert counts[b] == ref.size
+        _check(audio[b, : ref.size], ref)
+    # the pool repeats every 50 utterances, the frame counts every 7: 350 apart the utterances are the same
+    valid = np.arange(audio.shape[1])[None, :] < counts[:350, None]
+    assert np.array_equal(audio[:350][valid], audio[1050:1400][valid]) and np.array_equal(audio[:350][valid], audio[1750:2100][valid])

@@ -52,15 +52,25 @@ ms32 = timed(lambda: plan.normalize_device(d_audio, batch, n, d_max, None, d_out
 ms16 = timed(lambda: plan.normalize_device(d_audio, batch, n, d_max, None, d_out_i16=d_i16, stream=stream), 10)
 out["normalize_f32"] = {"samples": batch * n, "ms": ms32, "GBps": batch * n * 8 / (ms32 * 1e-3) / 1e9}
 out["normalize_i16"] = {"samples": batch * n, "ms": ms16, "GBps": batch * n * 6 / (ms16 * 1e-3) / 1e9}
-# --- host-buffer entry (H2D + kernel + D2H, synchronous): the PCIe-inclusive rate of configs[1]
-import time, tracks
-params = tracks.random_tracks(256, 500, seed0=1000)
-for prec, name in ((capi.PRECISION_F32, "f32"), (capi.PRECISION_F64, "f64")):
-    pl = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE), 44100.0, 1, prec), 250.0, 0)
-    pl.synthesize_host(params)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        audio, counts, _ = pl.synthesize_host(params)
-    dt = (time.perf_counter() - t0) / 5
-    out["host_entry_" + name] = {"batch": 256, "ms": dt * 1e3, "samples_per_s": float(counts.sum()) / dt}
+# --- host-buffer entry (H2D + kernel + D2H, synchronous): the PCIe-inclusive rate; host arrays allocated once
+import ctypes, time, tracks
+lib = g.load_library()
+pool = tracks.random_tracks(64, 500, seed0=1000)
+for bsz in (256, 4096):
+    params = np.ascontiguousarray(np.tile(pool, (bsz // 64, 1, 1)))
+    for prec, name in ((capi.PRECISION_F32, "f32"), (capi.PRECISION_F64, "f64")):
+        pl = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE), 44100.0, 1, prec), 250.0, 0)
+        n_out = pl.output_count(500)
+        audio = np.empty((bsz, n_out), dtype=np.float32)
+        counts = np.zeros(bsz, dtype=np.int64)
+        peaks = np.zeros(bsz, dtype=np.float32)
+        call = lambda: lib.gvtm_synthesize_batch_host(pl._h, ctypes.c_void_p(params.ctypes.data), None, bsz, 500,
+                                                      ctypes.c_void_p(audio.ctypes.data), n_out, ctypes.c_void_p(counts.ctypes.data),
+                                                      ctypes.c_void_p(peaks.ctypes.data))
+        assert call() == 0
+        t0 = time.perf_counter()
+        for _ in range(3):
+            assert call() == 0
+        dt = (time.perf_counter() - t0) / 3
+        out["host_entry_%s_batch%d" % (name, bsz)] = {"batch": bsz, "ms": dt * 1e3, "samples_per_s": float(counts.sum()) / dt}
 print(json.dumps(out))
