@@ -236,3 +236,20 @@ def test_special_case_frames(delay, layout):
     assert counts[0] == ref.size and np.isfinite(audio).all()
     assert _within(audio[0, : ref.size], ref, TOL_F64), _peak_err(audio[0, : ref.size], ref)
     assert np.array_equal(audio[2], audio[0])
+
+
+@pytest.mark.parametrize("precision,rows", [(capi.PRECISION_F64, 2), (capi.PRECISION_MIXED, 4), (capi.PRECISION_MIXED, 2)], ids=["f64x2", "mixedx4", "mixedx2"])
+def test_samples_do_not_depend_on_the_row_in_the_workgroup(precision, rows, monkeypatch):
+    """Several utterances per workgroup (GVTM_ROWS forces the shape a big batch would get): the same track must give the
+    same samples, bit for bit, in whichever DPP row and workgroup it lands (the resampler's per-row code is unrolled)."""
+    monkeypatch.setenv("GVTM_ROWS", str(rows))
+    plan = _plan(delay=2, precision=precision)
+    monkeypatch.delenv("GVTM_ROWS")
+    pool = tracks.random_tracks(3, 60, seed0=8100, consonant_heavy=True)
+    order = [0, 1, 2, 2, 0, 1, 1, 2, 0, 0, 0]  # every track in several rows and workgroups
+    audio, counts, _ = plan.synthesize_host(pool[order])
+    first = {t: order.index(t) for t in range(3)}
+    for b, t in enumerate(order):
+        assert np.array_equal(audio[b], audio[first[t]]), (b, t)
+    alone, _, _ = _plan(delay=2, precision=precision).synthesize_host(pool[:1])
+    assert np.array_equal(alone[0], audio[0])  # and the same as one utterance per workgroup
