@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, model5=False):
+def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, model5=False, model4=False):
     """Single-thread CPU throughput (output samples/s) on a bounded sample of the workload."""
     import numpy as np
     import oracle
@@ -55,6 +55,8 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, m
         model = {1: "1", 2: "2f:2", 3: "2f:3", 4: "2f:4"}[delay]
     if model5:
         model = "5"
+    if model4:
+        model = "4f" if float_model else "4"
     if exe_kind:
         kind = "reference"
         _, info = oracle.ref_synthesize(sample[0], model, output_rate, 250.0, config=voice, kind=exe_kind, repeat=2)
@@ -74,7 +76,7 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, m
             cfg5 = oracle.male5_config(output_rate)
             synth = lambda tr: oracle.synthesize5(cfg5, tr)[0]  # noqa: E731
         else:
-            cfg = oracle.male_config(output_rate, delay, float_model=int(float_model))
+            cfg = oracle.male_config(output_rate, delay, 1 if model4 else 0, float_model=int(float_model))
             synth = lambda tr: oracle.synthesize(cfg, tr)  # noqa: E731
         t0 = time.perf_counter()
         out = synth(sample[0])
@@ -103,9 +105,10 @@ def main():
                          "output bit-identical to it; f64 = VocalTractModel0<double>, model 0 (reported under 'extras'); "
                          "mixed = fp64 with an fp32 resampler")
     ap.add_argument("--output-rate", type=float, default=None, help="default 44100 (48000 with --model 5, the 5_male voice's own rate)")
-    ap.add_argument("--model", type=int, choices=[0, 5], default=0,
-                    help="0: the VocalTractModel0/2 path (default, BASELINE configs); 5: reference model 5 (VocalTractModel5<double,1>, "
-                         "its own kernel; fp64, --delay / --precision ignored)")
+    ap.add_argument("--model", type=int, choices=[0, 4, 5], default=0,
+                    help="0: the VocalTractModel0/2 path (default, BASELINE configs); 4: the 30+18-section tube of VocalTractModel4 "
+                         "(--precision f64 = reference model 4, f32 = VocalTractModel4<float,1>; --delay ignored); 5: reference model 5 "
+                         "(VocalTractModel5<double,1>, its own kernel; fp64, --delay / --precision ignored)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (other precision, batch 4096)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
@@ -142,15 +145,18 @@ def main():
     model5 = args.model == 5
     if args.output_rate is None:
         args.output_rate = 48000.0 if model5 else 44100.0
+    model4 = args.model == 4
     if model5:
         args.precision, args.delay = "f64", 1
+    if model4:
+        args.delay = 1
     voice = os.path.join(ROOT, "tests", "golden", "voice5_male.txt" if model5 else "voice_male.txt")
     cfgd = g.read_config_file(voice)
     prec = {"f64": capi.PRECISION_F64, "mixed": capi.PRECISION_MIXED, "f32": capi.PRECISION_F32}[args.precision]
     if model5:
         plan = g.Plan(g.config5_from_dict(cfgd, args.output_rate), 250.0, local_rank)
     else:
-        plan = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay, prec), 250.0, local_rank)
+        plan = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay, prec, capi.TUBE_30_18 if model4 else capi.TUBE_10_6), 250.0, local_rank)
     n_out = plan.output_count(args.frames)
 
     # synthetic tracks: SURVEY.md 8(d) config-2 generator; a pool of distinct tracks is tiled
@@ -199,7 +205,8 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            key = "batch%d_frames%d_delay%d_%s%s" % (args.batch, args.frames, args.delay, args.precision, "_model5" if model5 else "")
+            key = "batch%d_frames%d_delay%d_%s%s" % (args.batch, args.frames, args.delay, args.precision,
+                                                     "_model5" if model5 else ("_model4" if model4 else ""))
             traffic = json.load(f).get(key, {}).get("bytes")
     except (OSError, ValueError):
         pass
@@ -225,7 +232,7 @@ def main():
                             if model5 else
                             "batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel%s<%s> "
                             "semantics (SectionDelay %d), male voice, %.0f Hz out" % (
-                                args.batch, args.frames, args.frames * 0.004, "0" if args.delay == 1 else "2",
+                                args.batch, args.frames, args.frames * 0.004, "4" if model4 else ("0" if args.delay == 1 else "2"),
                                 "float" if args.precision == "f32" else "double", args.delay, args.output_rate),
                 "batch_per_gpu": args.batch,
                 "frames": args.frames,
@@ -247,7 +254,7 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
-        if world == 1 and not args.no_extras and not model5:
+        if world == 1 and not args.no_extras and not model5 and not model4:
             # the same kernel in the other arithmetic (BASELINE configs[1] names fp32, configs[3] an fp32/fp64
             # sweep) and at the batch BASELINE's target is quoted on; short runs, reported beside the headline
             def extra(precision, batch):
@@ -276,7 +283,7 @@ def main():
             other = "f32" if args.precision != "f32" else "f64"
             line["extras"] = [extra(other, args.batch), extra(args.precision, 4096), extra(other, 4096)]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=args.precision == "f32", model5=model5)
+            line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=args.precision == "f32", model5=model5, model4=model4)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
