@@ -14,7 +14,8 @@ from gama_tts_amd import capi  # noqa: E402
 import oracle  # noqa: E402
 import tracks  # noqa: E402
 
-BATCH, MAXF = 768, 96
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 768
+MAXF = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 rng = np.random.default_rng(20261004)
 frames = rng.integers(0, MAXF + 1, size=BATCH).astype(np.int32)
 frames[:4] = [0, 1, 2, MAXF]
