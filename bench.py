@@ -4,18 +4,28 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path (parameter frames in HBM -> audio samples in HBM) over
-one batch of synthetic utterances.  N=1 runs BASELINE.json configs[1] (batch 256, 500 frames
-= 2 s, "VTM0 fp32" = VocalTractModel0<float> semantics, 44.1 kHz out; the device output is
-bit-identical to that reference class); the fp64 model and batch 4096 ride along under "extras".  For N>1 the driver starts one process per
-GPU (torch.distributed.run); every rank synthesizes its own batch (weak scaling, independent
-utterances, no data-path collective — SURVEY.md 8e); the only communication is the barrier
-and the MAX of the elapsed time.
+one batch of synthetic utterances.
+
+Workload.  BASELINE.json's `metric` names no configuration, so the N=1 line is the largest
+single-GPU entry of `configs`: configs[3], "Batch=4096 30s long-form tracks, 2x oversampled
+tube, fp32 vs fp64 sweep" = 4096 utterances x 7500 frames, VocalTractModel2<TFloat,2>
+semantics (SectionDelay 2, 40 068 Hz internal), 44.1 kHz out; 1.97 GB of frames in and
+21.6 GB of samples out per launch, all resident in HBM.  The headline runs it in float (the
+reference's TFloat = float class, output bit-identical to it); `extras` carries the same
+workload in mixed and fp64 (the sweep), 4096 x 2 s and configs[1] (256 x 2 s, VTM0) in all
+three, and for each precision how far its samples are from the fp64 path's.  For N>1 the driver
+starts one process per GPU (torch.distributed.run): the global batch (default 4096 per GPU =
+configs[4]; `--global-batch G` fixes the total instead) is cut into contiguous shards by
+gama_tts_amd.shard.shard_range, every rank synthesizes its own shard (independent utterances,
+no data-path collective — SURVEY.md 8e); the only communication is the barrier and the MAX of
+the elapsed time.
 
 Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes per launch (64 B per
 input frame + 4 B per output sample) / the synthesis kernel's mean duration
-measured with HIP events on the launch stream.  `cpu_baseline` times the real reference
-(oracle/_ref, compiled from /root/reference in the build container; "port" = our C oracle when
-that binary is absent) on one host core over a bounded sample of the same workload.
+measured with HIP events on the launch stream; `roofline.valu` prices the same launches against
+the vector-ALU peak (the resource that actually binds).  `cpu_baseline` times the
+real reference (oracle/_ref, compiled from /root/reference in the build container; "port" = our
+C oracle when that binary is absent) on one host core over a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -28,12 +38,94 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = {"f32": 157.3, "mixed": 78.6, "f64": 78.6}  # vector peaks (same guide: fp32 157.3; fp64 vector = half)
+
+# Algorithmic flops: per internal step 367 (interpolation 16, radii 16, conversions 20, junction
+# coefficients 48, glottal lookup 16 + 49-tap decimator 98, source mix 17, tube 118, throat 4, filters 14) and per OUTPUT
+# sample 106 (26 taps x (coefficient interpolation 2 + multiply-add 2) + 2); transcendentals and divisions not counted.
+FLOP_PER_STEP = 367.0
+FLOP_PER_OUTPUT = 106.0
+
+DEFAULT_BATCH_PER_GPU = 4096   # configs[3] / configs[4]
+DEFAULT_FRAMES = 7500          # 30 s at 250 Hz
+DEFAULT_DELAY = 2              # "2x oversampled tube" = VocalTractModel2<TFloat,2>
+
+
+def rank_workload(args, rank, world):
+    """Which utterances of the global batch this rank synthesizes: (global_batch, lo, hi).
+
+    Contiguous shards from gama_tts_amd.shard.shard_range (the same function the gloo test drives); the global batch
+    is `--global-batch` (strong: fixed total) or `--batch` per GPU x world (weak, BASELINE configs[4] = 4096 x 8)."""
+    from gama_tts_amd.shard import shard_range
+
+    per_gpu = args.batch if args.batch is not None else DEFAULT_BATCH_PER_GPU
+    total = args.global_batch if args.global_batch is not None else per_gpu * world
+    lo, hi = shard_range(total, rank, world)
+    return total, lo, hi
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 4096, BASELINE configs[3] / [4])")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total utterances over all ranks, cut into contiguous shards (strong scaling); default --batch x ranks")
+    ap.add_argument("--frames", type=int, default=None, help="control frames per utterance, 4 ms each (default 7500 = 30 s)")
+    ap.add_argument("--delay", type=int, default=None, help="SectionDelay (default 2 = the 2x oversampled tube; 1 = VocalTractModel0)")
+    ap.add_argument("--precision", choices=["f64", "mixed", "f32"], default="f32",
+                    help="f32 (default) = the reference's TFloat = float classes (VocalTractModel0<float> = model 1, "
+                         "VocalTractModel2<float,D>), output bit-identical to them; f64 = TFloat = double (models 0 / 2 / 3), "
+                         "within 1e-9 of peak; mixed = fp64 with an fp32 resampler, 3e-7 of peak from the double model")
+    ap.add_argument("--output-rate", type=float, default=None, help="default 44100 (48000 with --model 5, the 5_male voice's own rate)")
+    ap.add_argument("--model", type=int, choices=[0, 4, 5], default=0,
+                    help="0: the VocalTractModel0/2 path (default, BASELINE configs); 4: the 30+18-section tube of VocalTractModel4 "
+                         "(--precision f64 = reference model 4, f32 = VocalTractModel4<float,1>; --delay ignored); 5: reference model 5 "
+                         "(VocalTractModel5<double,1>, its own kernel; fp64, --delay / --precision ignored); 4 and 5 default to 256 x 500 frames")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (other precisions and sizes)")
+    ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    args = ap.parse_args(argv)
+    if args.model in (4, 5):
+        # the other tubes keep round 1's 256 x 2 s workload (one utterance per workgroup at that size)
+        if args.batch is None:
+            args.batch = 256
+        if args.frames is None:
+            args.frames = 500
+        args.delay = 1
+        if args.model == 5:
+            args.precision = "f64"
+    if args.frames is None:
+        args.frames = DEFAULT_FRAMES
+    if args.delay is None:
+        args.delay = DEFAULT_DELAY
+    if args.output_rate is None:
+        args.output_rate = 48000.0 if args.model == 5 else 44100.0
+    return args
+
+
+def reference_class(precision, delay, model):
+    """The reference class whose output a precision reproduces, and how closely."""
+    t = "float" if precision == "f32" else "double"
+    if model == 5:
+        cls = "VocalTractModel5<double,1> (factory model 5)"
+    elif model == 4:
+        cls = "VocalTractModel4<%s,1>%s" % (t, " (factory model 4)" if t == "double" else "")
+    elif delay == 1:
+        cls = "VocalTractModel0<%s> (factory model %d)" % (t, 1 if t == "float" else 0)
+    else:
+        cls = "VocalTractModel2<%s,%d>%s" % (t, delay, " (factory model 3)" if (t == "double" and delay == 3) else "")
+    how = {"f32": "bit-identical float32 samples (tests/test_gpu_parity_f32.py)",
+           "f64": "<= 1e-9 of peak on 2 s, 5e-9 after 30 s (tests/test_gpu_parity.py)",
+           "mixed": "3e-7 of peak (fp32 resampler; tests/test_gpu_parity.py)"}[precision]
+    return cls, how
 
 
 def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, model5=False, model4=False):
     """Single-thread CPU throughput (output samples/s) on a bounded sample of the workload."""
-    import numpy as np
     import oracle
     voice = oracle.VOICE5_MALE if model5 else oracle.VOICE_MALE
 
@@ -59,8 +151,8 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, m
         model = "4f" if float_model else "4"
     if exe_kind:
         kind = "reference"
-        _, info = oracle.ref_synthesize(sample[0], model, output_rate, 250.0, config=voice, kind=exe_kind, repeat=2)
-        per_rep = float(info["sec"]) / 2
+        _, info = oracle.ref_synthesize(sample[0], model, output_rate, 250.0, config=voice, kind=exe_kind, repeat=1)
+        per_rep = float(info["sec"])
         repeat = max(1, int(budget_s / max(per_rep, 1e-6) / len(sample)))
         total_samples = 0
         total_sec = 0.0
@@ -79,7 +171,7 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, m
             cfg = oracle.male_config(output_rate, delay, 1 if model4 else 0, float_model=int(float_model))
             synth = lambda tr: oracle.synthesize(cfg, tr)  # noqa: E731
         t0 = time.perf_counter()
-        out = synth(sample[0])
+        synth(sample[0])
         per = time.perf_counter() - t0
         repeat = max(1, int(budget_s / max(per, 1e-6) / len(sample)))
         total_samples = 0
@@ -92,30 +184,21 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, m
     return {"value": total_samples / total_sec, "unit": "samples/s", "cores": 1, "kind": kind, "sample": desc}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
-    ap.add_argument("--frames", type=int, default=500, help="control frames per utterance (4 ms each)")
-    ap.add_argument("--delay", type=int, default=1, help="SectionDelay (1 = VocalTractModel0)")
-    ap.add_argument("--precision", choices=["f64", "mixed", "f32"], default="f32",
-                    help="f32 (default; BASELINE configs[1] is 'VTM0 fp32') = VocalTractModel0<float>, reference model 1, "
-                         "output bit-identical to it; f64 = VocalTractModel0<double>, model 0 (reported under 'extras'); "
-                         "mixed = fp64 with an fp32 resampler")
-    ap.add_argument("--output-rate", type=float, default=None, help="default 44100 (48000 with --model 5, the 5_male voice's own rate)")
-    ap.add_argument("--model", type=int, choices=[0, 4, 5], default=0,
-                    help="0: the VocalTractModel0/2 path (default, BASELINE configs); 4: the 30+18-section tube of VocalTractModel4 "
-                         "(--precision f64 = reference model 4, f32 = VocalTractModel4<float,1>; --delay ignored); 5: reference model 5 "
-                         "(VocalTractModel5<double,1>, its own kernel; fp64, --delay / --precision ignored)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (other precision, batch 4096)")
-    ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
-    args = ap.parse_args()
+def traffic_entry(batch, frames, delay, precision, model):
+    """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            key = "batch%d_frames%d_delay%d_%s%s" % (batch, frames, delay, precision,
+                                                     "_model5" if model == 5 else ("_model4" if model == 4 else ""))
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
 
-    import numpy as np
+
+def main():
+    args = parse_args()
+
+    import numpy as np  # noqa: F401
     import torch
 
     import gama_tts_amd as g
@@ -143,36 +226,41 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     model5 = args.model == 5
-    if args.output_rate is None:
-        args.output_rate = 48000.0 if model5 else 44100.0
     model4 = args.model == 4
-    if model5:
-        args.precision, args.delay = "f64", 1
-    if model4:
-        args.delay = 1
+    global_batch, lo, hi = rank_workload(args, rank, world)
+    batch = hi - lo
     voice = os.path.join(ROOT, "tests", "golden", "voice5_male.txt" if model5 else "voice_male.txt")
     cfgd = g.read_config_file(voice)
-    prec = {"f64": capi.PRECISION_F64, "mixed": capi.PRECISION_MIXED, "f32": capi.PRECISION_F32}[args.precision]
-    if model5:
-        plan = g.Plan(g.config5_from_dict(cfgd, args.output_rate), 250.0, local_rank)
-    else:
-        plan = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay, prec, capi.TUBE_30_18 if model4 else capi.TUBE_10_6), 250.0, local_rank)
-    n_out = plan.output_count(args.frames)
+    PREC = {"f64": capi.PRECISION_F64, "mixed": capi.PRECISION_MIXED, "f32": capi.PRECISION_F32}
 
-    # synthetic tracks: SURVEY.md 8(d) config-2 generator; a pool of distinct tracks is tiled
-    # over the batch so that host-side generation stays cheap for big batches
-    pool = min(args.batch, 256)
-    host_pool = tracks.random_tracks(pool, args.frames, seed0=1000 + 100000 * rank, consonant_heavy=model5)
-    reps = (args.batch + pool - 1) // pool
+    def make_plan(precision, delay):
+        if model5:
+            return g.Plan(g.config5_from_dict(cfgd, args.output_rate), 250.0, local_rank)
+        return g.Plan(g.config_from_dict(cfgd, args.output_rate, delay, PREC[precision], capi.TUBE_30_18 if model4 else capi.TUBE_10_6),
+                      250.0, local_rank)
+
+    plan = make_plan(args.precision, args.delay)
+    n_out = plan.output_count(args.frames)
+    steps_per_utt = args.frames * int(plan.info.control_steps)
+
+    # synthetic tracks: SURVEY.md 8(d) config-2 generator, seeded by GLOBAL utterance id; a pool of distinct
+    # tracks is tiled over the shard so that host-side generation stays cheap for big batches
+    pool = max(1, min(batch, 256))
+    host_pool = tracks.random_tracks(pool, args.frames, seed0=1000 + lo, consonant_heavy=model5)
     d_pool = torch.from_numpy(host_pool).to(dev)
-    d_params = d_pool.repeat((reps, 1, 1))[: args.batch].contiguous()
-    d_audio = torch.empty((args.batch, n_out), dtype=torch.float32, device=dev)
-    d_counts = torch.zeros(args.batch, dtype=torch.int64, device=dev)
-    d_max = torch.zeros(args.batch, dtype=torch.float32, device=dev)
+
+    def tiled(n, frames):
+        reps = (n + pool - 1) // pool
+        return d_pool[:, :frames].repeat((reps, 1, 1))[:n].contiguous()
+
+    d_params = tiled(batch, args.frames)
+    d_audio = torch.empty((max(batch, 1), n_out), dtype=torch.float32, device=dev)
+    d_counts = torch.zeros(max(batch, 1), dtype=torch.int64, device=dev)
+    d_max = torch.zeros(max(batch, 1), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        plan.synthesize_device(d_params, args.batch, args.frames, d_audio, n_out, None, d_counts, d_max, stream)
+        plan.synthesize_device(d_params, batch, args.frames, d_audio, n_out, None, d_counts, d_max, stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -191,27 +279,22 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = plan.take_kernel_ms()
     plan.set_timing(False)
-    assert int(d_counts.min().item()) == n_out and int(d_counts.max().item()) == n_out
+    if batch:
+        assert int(d_counts[:batch].min().item()) == n_out and int(d_counts[:batch].max().item()) == n_out
 
     from gama_tts_amd.shard import max_over_ranks
     elapsed = max_over_ranks(elapsed, dist, dev if args.dist_backend == "nccl" else None)
 
-    total_samples = float(n_out) * args.batch * world * args.steps
+    total_samples = float(n_out) * global_batch * args.steps
     value = total_samples / elapsed
-    algo_bytes = float(args.batch) * (args.frames * 64.0 + n_out * 4.0)
+    algo_bytes = float(batch) * (args.frames * 64.0 + n_out * 4.0)
+    algo_flops = float(batch) * (steps_per_utt * FLOP_PER_STEP + n_out * FLOP_PER_OUTPUT)
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
-
-    # HBM traffic of this workload as measured with rocprofv3 PMC passes (profiles/traffic.json)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            key = "batch%d_frames%d_delay%d_%s%s" % (args.batch, args.frames, args.delay, args.precision,
-                                                     "_model5" if model5 else ("_model4" if model4 else ""))
-            traffic = json.load(f).get(key, {}).get("bytes")
-    except (OSError, ValueError):
-        pass
+    tflops = algo_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None
 
     if rank == 0:
+        tr = traffic_entry(batch, args.frames, args.delay, args.precision, args.model)
+        ref_cls, ref_how = reference_class(args.precision, args.delay, args.model)
         line = {
             "metric": "audio samples/sec (whole node), batched VTM @%s" % ("48kHz" if model5 and args.output_rate == 48000.0 else "44.1kHz"),
             "value": value,
@@ -221,24 +304,25 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.global_batch is None else "strong",
             "vs_baseline": None,
-            "dtype": "f64" if args.precision == "f64" else "f32",
+            "dtype": args.precision,
             "data": "synthetic",
             "real_time_factor": value / args.output_rate,
             "config": {
-                "workload": ("batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel5<double> (reference "
-                             "model 5), 5_male voice, %.0f Hz out" % (args.batch, args.frames, args.frames * 0.004, args.output_rate))
-                            if model5 else
-                            "batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, VocalTractModel%s<%s> "
-                            "semantics (SectionDelay %d), male voice, %.0f Hz out" % (
-                                args.batch, args.frames, args.frames * 0.004, "4" if model4 else ("0" if args.delay == 1 else "2"),
-                                "float" if args.precision == "f32" else "double", args.delay, args.output_rate),
-                "batch_per_gpu": args.batch,
+                "workload": ("batch=%d/GPU x %d frames (%.1f s) synthetic parameter tracks, %s semantics, %s voice, %.0f Hz out%s" % (
+                    batch, args.frames, args.frames * 0.004, ref_cls.split(" (")[0], "5_male" if model5 else "male", args.output_rate,
+                    " = BASELINE configs[3] (4096 x 30 s, 2x oversampled tube)" if (batch, args.frames, args.delay, args.model) == (4096, 7500, 2, 0) else "")),
+                "batch_per_gpu": batch,
+                "global_batch": global_batch,
                 "frames": args.frames,
+                "section_delay": args.delay,
+                "internal_rate_hz": float(plan.info.internal_rate_hz),
                 "samples_per_utterance": n_out,
                 "precision": args.precision,
-                "parallelism": "utterance-sharded x%d, no collectives" % world,
+                "reproduces": ref_cls,
+                "parity": ref_how,
+                "parallelism": "utterance-sharded x%d (contiguous shards), no collectives" % world,
             },
             "roofline": {
                 "bound": "hbm",
@@ -246,47 +330,95 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": traffic,
-                "kernel": "gvtm::m5::vtm5_synth_kernel" if model5 else (
-                    "gvtm::v2::vtm_synth_kernel" if os.environ.get("GVTM_KERNEL", "2") != "1" else "gvtm::v1::vtm_synth_kernel"),
+                "traffic": tr.get("bytes") if tr else None,
+                "traffic_source": ("replayed from profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (%s)"
+                                   % ", ".join(tr.get("source", []))) if tr else None,
+                "kernel": "gvtm::m5::vtm5_synth_kernel" if model5 else "gvtm::v2::vtm_synth_kernel",
                 "kernel_ms": kernel_ms,
                 "launches_timed": launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
+                # the resource that binds: vector-ALU issue of lane-sparse serial code
+                "valu": {
+                    "achieved_tflops": tflops,
+                    "peak": VALU_PEAK_TFLOPS[args.precision],
+                    "unit": "TFLOP/s",
+                    "frac": (tflops / VALU_PEAK_TFLOPS[args.precision]) if tflops else None,
+                    "algorithmic_flops_per_launch": algo_flops,
+                    "flop_per_output_sample": algo_flops / (float(batch) * n_out) if batch else None,
+                    "valu_active": tr.get("valu_active") if tr else None,
+                    "valu_active_source": tr.get("valu_active_source") if tr else None,
+                },
             },
         }
         if world == 1 and not args.no_extras and not model5 and not model4:
-            # the same kernel in the other arithmetic (BASELINE configs[1] names fp32, configs[3] an fp32/fp64
-            # sweep) and at the batch BASELINE's target is quoted on; short runs, reported beside the headline
-            def extra(precision, batch):
-                pl = g.Plan(g.config_from_dict(cfgd, args.output_rate, args.delay,
-                                               {"f64": capi.PRECISION_F64, "mixed": capi.PRECISION_MIXED, "f32": capi.PRECISION_F32}[precision]),
-                            250.0, local_rank)
-                reps_e = (batch + pool - 1) // pool
-                dp = d_pool.repeat((reps_e, 1, 1))[:batch].contiguous()
-                da = torch.empty((batch, n_out), dtype=torch.float32, device=dev)
-                dc = torch.zeros(batch, dtype=torch.int64, device=dev)
-                for _ in range(2):
-                    pl.synthesize_device(dp, batch, args.frames, da, n_out, None, dc, None, stream)
-                torch.cuda.synchronize()
-                pl.set_timing(True)
-                t_e = time.perf_counter()
-                n_e = 5
-                for _ in range(n_e):
-                    pl.synthesize_device(dp, batch, args.frames, da, n_out, None, dc, None, stream)
-                torch.cuda.synchronize()
-                el = time.perf_counter() - t_e
-                kms, _ = pl.take_kernel_ms()
-                assert int(dc.min().item()) == n_out
-                del da, dp
-                return {"precision": precision, "batch": batch, "value": float(n_out) * batch * n_e / el, "unit": "samples/s",
-                        "kernel_ms": kms, "real_time_factor": float(n_out) * batch * n_e / el / args.output_rate}
-            other = "f32" if args.precision != "f32" else "f64"
-            line["extras"] = [extra(other, args.batch), extra(args.precision, 4096), extra(other, 4096)]
+            line["extras"] = extras(args, g, make_plan, tiled, d_audio, d_counts, stream, n_out)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=args.precision == "f32", model5=model5, model4=model4)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def extras(args, g, make_plan, tiled, d_audio, d_counts, stream, n_out_main):
+    """Other precisions and sizes on the same GPU, short runs beside the headline: the fp32 / fp64 sweep of
+    configs[3], the batch BASELINE's target is quoted on with 2 s tracks, and configs[1] (256 x 2 s, VTM0).  The
+    256 x 2 s entries also say how far each precision's samples are from the fp64 path's (which the tests hold
+    within 1e-9 of the reference's double model): max |x - x64| / max |x64| over the batch."""
+    import torch
+
+    out = []
+    flat = d_audio.view(-1)
+
+    def run(precision, batch, frames, delay, n_timed, keep=None):
+        pl = make_plan(precision, delay)
+        n_out = pl.output_count(frames)
+        steps = frames * int(pl.info.control_steps)
+        dp = tiled(batch, frames)
+        need = batch * n_out
+        da = (flat[:need] if need <= flat.numel() else torch.empty(need, dtype=torch.float32, device=flat.device)).view(batch, n_out)
+        dc = d_counts[:batch] if batch <= d_counts.numel() else torch.zeros(batch, dtype=torch.int64, device=flat.device)
+        pl.synthesize_device(dp, batch, frames, da, n_out, None, dc, None, stream)
+        torch.cuda.synchronize()
+        pl.set_timing(True)
+        t_e = time.perf_counter()
+        for _ in range(n_timed):
+            pl.synthesize_device(dp, batch, frames, da, n_out, None, dc, None, stream)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t_e
+        kms, _ = pl.take_kernel_ms()
+        assert int(dc.min().item()) == n_out
+        cls, _how = reference_class(precision, delay, 0)
+        flops = float(batch) * (steps * FLOP_PER_STEP + n_out * FLOP_PER_OUTPUT)
+        e = {"precision": precision, "batch": batch, "frames": frames, "section_delay": delay, "reproduces": cls,
+             "value": float(n_out) * batch * n_timed / el, "unit": "samples/s", "kernel_ms": kms,
+             "real_time_factor": float(n_out) * batch * n_timed / el / args.output_rate,
+             "hbm_gbs": float(batch) * (frames * 64.0 + n_out * 4.0) / (kms * 1e-3) / 1e9,
+             "valu_tflops": flops / (kms * 1e-3) / 1e12, "valu_frac": flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS[precision]}
+        if keep is not None:
+            keep[precision] = da.clone()
+        del dp
+        return e
+
+    main_key = (args.precision, args.frames, args.delay)
+    per_gpu = args.batch if args.batch is not None else DEFAULT_BATCH_PER_GPU
+    # the sweep of configs[3] at the headline's size
+    for p in ("mixed", "f64", "f32"):
+        if (p, args.frames, args.delay) != main_key:
+            out.append(run(p, per_gpu, args.frames, args.delay, 2 if args.frames > 2000 else 5))
+    # 4096 x 2 s, VocalTractModel0 semantics (BASELINE's ">= 4096 utterances" target)
+    for p in ("f32", "mixed", "f64"):
+        out.append(run(p, 4096, 500, 1, 5))
+    # configs[1]: 256 x 2 s, VocalTractModel0 semantics
+    keep = {}
+    small = [run(p, 256, 500, 1, 10, keep) for p in ("f64", "mixed", "f32")]
+    ref = keep["f64"].double()
+    peak = ref.abs().amax(dim=1).clamp_min(1e-300)
+    for e in small:
+        dev_ = ((keep[e["precision"]].double() - ref).abs().amax(dim=1) / peak)
+        e["vs_f64_path"] = {"worst": float(dev_.max().item()), "median": float(dev_.median().item()),
+                            "meets_1e-5": bool(dev_.max().item() <= 1e-5)}
+    out.extend(small)
+    return out
 
 
 if __name__ == "__main__":

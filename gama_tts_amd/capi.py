@@ -94,19 +94,21 @@ class Config5(ctypes.Structure):
     ]
 
 
-def library_path():
-    return os.path.join(_HERE, "lib", _LIB_NAME)
+def library_path(diagnostics=False):
+    return os.path.join(_HERE, "lib", "libgama_vtm_diag.so" if diagnostics else _LIB_NAME)
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Loads libgama_vtm.so from the in-tree build; raises if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = os.environ.get("GVTM_LIBRARY") or library_path()
+def load_library(diagnostics=False):
+    """Loads libgama_vtm.so from the in-tree build; raises if it has not been built.
+
+    diagnostics=True loads libgama_vtm_diag.so instead: the same kernels behind a C ABI built with -DGVTM_DIAGNOSTICS,
+    which adds the gvtm_debug_* hooks (tests and tools only; the product library exports none of them)."""
+    if diagnostics in _libs:
+        return _libs[diagnostics]
+    path = library_path(True) if diagnostics else (os.environ.get("GVTM_LIBRARY") or library_path())
     # libgama_vtm.so and PyTorch-ROCm both need libamdhip64.so.7 and a process can hold only one
     # copy: whichever loads first serves both.  PyTorch only works with the copy bundled in its
     # wheel, so when torch is installed let it load first (bench.py/tests share device pointers
@@ -136,6 +138,8 @@ def load_library():
     L.gvtm_plan_table.restype = i32
     L.gvtm_output_count.argtypes = [vp, sz]
     L.gvtm_output_count.restype = sz
+    L.gvtm_output_capacity.argtypes = [vp, sz]
+    L.gvtm_output_capacity.restype = sz
     L.gvtm_synthesize_batch_device.argtypes = [vp, vp, vp, sz, sz, vp, sz, vp, vp, vp]
     L.gvtm_synthesize_batch_device.restype = i32
     L.gvtm_synthesize_batch_host.argtypes = [vp, vp, vp, sz, sz, vp, sz, vp, vp]
@@ -152,7 +156,15 @@ def load_library():
     L.gvtm_plan_set_timing.restype = i32
     L.gvtm_plan_take_kernel_ms.argtypes = [vp, ctypes.POINTER(i32)]
     L.gvtm_plan_take_kernel_ms.restype = dbl
-    _lib = L
+    if diagnostics:
+        L.gvtm_debug_set_rows.argtypes = [vp, i32]
+        L.gvtm_debug_set_rows.restype = i32
+        L.gvtm_debug_set_taps.argtypes = [vp, vp]
+        L.gvtm_debug_set_phase_cycles.argtypes = [vp, vp]
+        L.gvtm_debug_dpp_selftest.argtypes = [vp, vp]
+        L.gvtm_debug_short_math.argtypes = [i32, vp, sz, vp]
+        L.gvtm_debug_device_float_math.argtypes = [vp, i32, vp, sz, vp]
+    _libs[diagnostics] = L
     return L
 
 
@@ -296,8 +308,10 @@ def _ptr(x):
 class Plan:
     """Owns a gvtm_plan.  device=DEVICE_NONE gives a design-only plan (no GPU needed)."""
 
-    def __init__(self, config, control_rate=250.0, device=0):
-        self._lib = load_library()
+    def __init__(self, config, control_rate=250.0, device=0, diagnostics=False, rows=0):
+        """diagnostics=True binds the plan to libgama_vtm_diag.so (gvtm_debug_* hooks); rows (diagnostics only) forces
+        the utterances per workgroup, i.e. the kernel shape a big batch would get."""
+        self._lib = load_library(diagnostics)
         self._h = ctypes.c_void_p()
         self.config = config
         create = self._lib.gvtm_plan_create_model5 if isinstance(config, Config5) else self._lib.gvtm_plan_create
@@ -306,6 +320,10 @@ class Plan:
         info = Info()
         self._check(self._lib.gvtm_plan_info(self._h, ctypes.byref(info)))
         self.info = info
+        if rows:
+            if not diagnostics:
+                raise ValueError("rows can only be forced on a diagnostics plan")
+            self._check(self._lib.gvtm_debug_set_rows(self._h, int(rows)))
 
     def _check(self, rc):
         if rc != 0:
@@ -330,10 +348,11 @@ class Plan:
         return buf[:n].copy()
 
     def output_count(self, frames):
-        n = self._lib.gvtm_output_count(self._h, int(frames))
-        if n == ctypes.c_size_t(-1).value:
-            raise GvtmError(_STATUS_UNSUPPORTED, self._lib.gvtm_last_error().decode())
-        return int(n)
+        return int(self._lib.gvtm_output_count(self._h, int(frames)))
+
+    def output_capacity(self, max_frames):
+        """Row length that holds every utterance of a ragged batch (> output_count(max_frames) on down-sampling plans)."""
+        return int(self._lib.gvtm_output_capacity(self._h, int(max_frames)))
 
     def set_timing(self, enabled):
         self._check(self._lib.gvtm_plan_set_timing(self._h, int(bool(enabled))))
@@ -355,7 +374,7 @@ class Plan:
         params = np.ascontiguousarray(params, dtype=np.float32)
         assert params.ndim == 3 and params.shape[2] == N_PARAM
         batch, frames = params.shape[:2]
-        stride = self.output_count(frames)
+        stride = self.output_count(frames) if frame_counts is None else self.output_capacity(frames)
         audio = np.zeros((batch, stride), dtype=np.float32)
         counts = np.zeros(batch, dtype=np.int64)
         maxabs = np.zeros(batch, dtype=np.float32)

@@ -57,14 +57,35 @@ struct EventPair {
 	hipEvent_t start = nullptr, stop = nullptr;
 };
 
+// Makes the plan's device current for the duration of an entry point and gives the caller's device back afterwards.
+class DeviceScope {
+public:
+	explicit DeviceScope(int device)
+	{
+		if (hipGetDevice(&previous_) != hipSuccess) previous_ = -1;
+		status_ = (previous_ == device) ? hipSuccess : hipSetDevice(device);
+		changed_ = status_ == hipSuccess && previous_ != device;
+	}
+	~DeviceScope()
+	{
+		if (changed_ && previous_ >= 0) (void) hipSetDevice(previous_);
+	}
+	DeviceScope(const DeviceScope&) = delete;
+	DeviceScope& operator=(const DeviceScope&) = delete;
+	hipError_t status() const { return status_; }
+private:
+	int previous_ = -1;
+	bool changed_ = false;
+	hipError_t status_ = hipSuccess;
+};
+
 } // namespace
 
 struct gvtm_plan {
 	gvtm::Design design;
 	int device = 0;
 	int precision = GVTM_PRECISION_F64;
-	int generation = 2; // kernel generation; GVTM_KERNEL=1 selects the round-1 baseline for A/B runs
-	int rows = 0;       // utterances per workgroup; 0 = by batch size, GVTM_ROWS=1|2|4 forces it (tests)
+	int rows = 0;       // utterances per workgroup; 0 = by batch size (a diagnostics build can force it)
 	// design tables on the device: double, or float (as designed) for GVTM_PRECISION_F32
 	void* d_wavetable = nullptr;
 	void* d_fir = nullptr;
@@ -76,8 +97,8 @@ struct gvtm_plan {
 	DeviceBuffer s_params, s_frames, s_audio, s_counts, s_maxabs;
 	// kernel timing (HIP events on the launch stream)
 	bool timing = false;
-	double* debug_taps = nullptr; // device pointer, see gvtm_debug_set_taps
-	unsigned long long* phase_cycles = nullptr; // device pointer, see gvtm_debug_set_phase_cycles
+	double* debug_taps = nullptr; // device pointer (diagnostics builds: gvtm_debug_set_taps)
+	unsigned long long* phase_cycles = nullptr; // device pointer (diagnostics builds: gvtm_debug_set_phase_cycles)
 	std::vector<EventPair> pending;
 	std::vector<EventPair> pool;
 	// host-buffer entry on large batches: kernels on one stream, copies back on another (created on first use)
@@ -102,7 +123,7 @@ void free_plan(gvtm_plan* p)
 		delete p;
 		return;
 	}
-	(void) hipSetDevice(p->device);
+	DeviceScope scope(p->device);
 	if (p->d_wavetable) (void) hipFree(p->d_wavetable);
 	if (p->d_fir) (void) hipFree(p->d_fir);
 	if (p->d_src_h) (void) hipFree(p->d_src_h);
@@ -160,8 +181,6 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 		const std::string why = gvtm::design_plan(*config, control_rate, plan->design);
 		if (!why.empty()) return fail(GVTM_ERR_INVALID_ARGUMENT, why);
 		plan->precision = config->precision;
-		if (const char* gen = std::getenv("GVTM_KERNEL")) plan->generation = (gen[0] == '1') ? 1 : 2;
-		if (const char* rows = std::getenv("GVTM_ROWS")) plan->rows = std::atoi(rows);
 
 		if (device == GVTM_DEVICE_NONE) {
 			// design-only plan: info, tables and output counts work, synthesis reports NO_DEVICE
@@ -176,7 +195,8 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 		}
 		if (device < 0 || device >= n) return fail(GVTM_ERR_NO_DEVICE, "device index out of range");
 		plan->device = device;
-		if ((e = hipSetDevice(device)) != hipSuccess) return fail_hip(e, "hipSetDevice");
+		DeviceScope scope(device);
+		if ((e = scope.status()) != hipSuccess) return fail_hip(e, "hipSetDevice");
 		hipDeviceProp_t prop;
 		if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail_hip(e, "hipGetDeviceProperties");
 		if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -223,7 +243,8 @@ int gvtm_plan_create_model5(const gvtm5_config* config, double control_rate, int
 		if (e != hipSuccess || n <= 0) return fail(GVTM_ERR_NO_DEVICE, "no HIP device available (libgama_vtm has no CPU path)");
 		if (device < 0 || device >= n) return fail(GVTM_ERR_NO_DEVICE, "device index out of range");
 		plan->device = device;
-		if ((e = hipSetDevice(device)) != hipSuccess) return fail_hip(e, "hipSetDevice");
+		DeviceScope scope(device);
+		if ((e = scope.status()) != hipSuccess) return fail_hip(e, "hipSetDevice");
 		hipDeviceProp_t prop;
 		if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail_hip(e, "hipGetDeviceProperties");
 		if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -290,12 +311,26 @@ int gvtm_plan_table(const gvtm_plan* plan, int which, double* out, size_t capaci
 size_t gvtm_output_count(const gvtm_plan* plan, size_t n_frames)
 {
 	if (!plan) return static_cast<size_t>(-1);
-	uint64_t n = 0;
-	if (!gvtm::output_count_for_steps(plan->design.k, static_cast<uint64_t>(n_frames) * plan->design.k.control_steps, n)) {
-		g_last_error = "this frame count triggers the reference SampleRateConverter's flush overrun (ring-wrap defect); not reproduced";
-		return static_cast<size_t>(-1);
-	}
-	return static_cast<size_t>(n);
+	const gvtm::DeviceConstants& k = plan->design.k;
+	return static_cast<size_t>(gvtm::src_output_count(k.time_inc, k.pad, k.upsampling, static_cast<uint64_t>(n_frames) * k.control_steps));
+}
+
+size_t gvtm_output_capacity(const gvtm_plan* plan, size_t max_frames)
+{
+	if (!plan) return static_cast<size_t>(-1);
+	const gvtm::DeviceConstants& k = plan->design.k;
+	return static_cast<size_t>(gvtm::src_output_capacity(k.time_inc, k.pad, k.upsampling, static_cast<uint64_t>(max_frames) * k.control_steps));
+}
+
+#ifdef GVTM_DIAGNOSTICS
+/* ---- hooks of the diagnostics build (libgama_vtm_diag.so; tests and tools only, not in the public header) ---- */
+
+/* Forces the utterances per workgroup (1, 2, 4, 8; 0 = by batch size), i.e. the kernel shape a big batch would get. */
+int gvtm_debug_set_rows(gvtm_plan* plan, int rows)
+{
+	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
+	plan->rows = rows;
+	return GVTM_OK;
 }
 
 /* Test hook (not in the public header): device buffer [batch][max_frames*control_steps][8] of
@@ -322,7 +357,8 @@ int gvtm_debug_set_phase_cycles(gvtm_plan* plan, unsigned long long* d_cycles)
 int gvtm_debug_dpp_selftest(gvtm_plan* plan, int* out)
 {
 	if (!plan || !out || plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_INVALID_ARGUMENT, "needs a device plan");
-	hipError_t e = hipSetDevice(plan->device);
+	DeviceScope scope(plan->device);
+	hipError_t e = scope.status();
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	int* d = nullptr;
 	if ((e = hipMalloc(reinterpret_cast<void**>(&d), gvtm::kDppSelftestInts * sizeof(int))) != hipSuccess) return fail_hip(e, "hipMalloc");
@@ -361,7 +397,8 @@ int gvtm_debug_device_float_math(gvtm_plan* plan, int kind, const float* x, size
 {
 	if (!plan || !x || !out || kind < 0 || kind > 3) return fail(GVTM_ERR_INVALID_ARGUMENT, "bad argument");
 	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan");
-	hipError_t e = hipSetDevice(plan->device);
+	DeviceScope scope(plan->device);
+	hipError_t e = scope.status();
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	float *dx = nullptr, *dout = nullptr;
 	if ((e = hipMalloc(reinterpret_cast<void**>(&dx), n * sizeof(float))) != hipSuccess) return fail_hip(e, "hipMalloc");
@@ -374,6 +411,8 @@ int gvtm_debug_device_float_math(gvtm_plan* plan, int kind, const float* x, size
 	if (e != hipSuccess) return fail_hip(e, "float math probe");
 	return GVTM_OK;
 }
+
+#endif /* GVTM_DIAGNOSTICS */
 
 size_t gvtm_tracks_frame_count(const gvtm_track_config* config, const gvtm_event* events, size_t n_events)
 {
@@ -397,7 +436,8 @@ int gvtm_generate_tracks_device(int device, const gvtm_track_config* config, con
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(GVTM_ERR_NO_DEVICE, "no HIP device available (track generation has no CPU path)");
 	if (device < 0 || device >= n) return fail(GVTM_ERR_NO_DEVICE, "device index out of range");
-	hipError_t e = hipSetDevice(device);
+	DeviceScope scope(device);
+	hipError_t e = scope.status();
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	args.events = d_events;
 	args.event_offsets = d_event_offsets;
@@ -424,7 +464,8 @@ int gvtm_generate_tracks_host(int device, const gvtm_track_config* config, const
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(GVTM_ERR_NO_DEVICE, "no HIP device available (track generation has no CPU path)");
 	if (device < 0 || device >= n) return fail(GVTM_ERR_NO_DEVICE, "device index out of range");
-	hipError_t e = hipSetDevice(device);
+	DeviceScope scope(device);
+	hipError_t e = scope.status();
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	const size_t n_events = static_cast<size_t>(event_offsets[batch]);
 	DeviceBuffer d_ev, d_off, d_par, d_cnt, d_dr;
@@ -460,7 +501,7 @@ double gvtm_plan_take_kernel_ms(gvtm_plan* plan, int* launches_out)
 {
 	if (launches_out) *launches_out = 0;
 	if (!plan || plan->device == GVTM_DEVICE_NONE || plan->pending.empty()) return -1.0;
-	(void) hipSetDevice(plan->device);
+	DeviceScope scope(plan->device);
 	double total = 0.0;
 	int n = 0;
 	for (auto& ev : plan->pending) {
@@ -489,23 +530,27 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	if (static_cast<unsigned long long>(max_frames) * plan->design.k.control_steps + 4096ull >= (1ull << 31)) {
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "max_frames * control_steps does not fit the 31-bit step counter");
 	}
-	const size_t need = gvtm_output_count(plan, max_frames);
-	if (need == static_cast<size_t>(-1)) return GVTM_ERR_UNSUPPORTED;
-	if (audio_stride < need) {
+	if (audio_stride < gvtm_output_count(plan, max_frames)) {
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
 	}
 	const bool model5 = plan->design.model5;
-	const int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows, plan->design.k.section_delay);
-	if ((model5 ? gvtm::synth5_lds_bytes() : gvtm::synth_lds_bytes(plan->precision, plan->generation, rows)) > 160 * 1024) {
+	const gvtm::DeviceConstants& k = plan->design.k;
+	constexpr size_t kLdsPerWorkgroup = 160 * 1024;
+	int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows, k.section_delay);
+	// a shape whose rings do not fit (down-sampling plans carry the reference's 1024-sample ring per row) gives way to
+	// the next smaller one
+	while (!model5 && rows > 1 && gvtm::synth_lds_bytes(k, plan->precision, rows) > kLdsPerWorkgroup) rows /= 2;
+	if ((model5 ? gvtm::synth5_lds_bytes() : gvtm::synth_lds_bytes(k, plan->precision, rows)) > kLdsPerWorkgroup) {
 		return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
 	}
 
-	hipError_t e = hipSetDevice(plan->device);
+	DeviceScope scope(plan->device);
+	hipError_t e = scope.status();
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
 
 	gvtm::SynthArgs args;
-	args.k = plan->design.k;
+	args.k = k;
 	args.kconst = plan->d_consts;
 	args.params = d_params;
 	args.frame_counts = d_frame_counts;
@@ -519,6 +564,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	args.max_frames = max_frames;
 	args.audio_stride = audio_stride;
 	args.batch = batch;
+	args.xr = model5 ? 0 : gvtm::synth_ring_length(k, plan->precision, rows);
 	args.debug_taps = plan->debug_taps;
 	args.phase_cycles = plan->phase_cycles;
 	args.k5const = plan->d_consts5;
@@ -535,7 +581,7 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 		if ((e = hipEventRecord(ev.start, stream)) != hipSuccess) return fail_hip(e, "hipEventRecord");
 	}
 	e = model5 ? gvtm::launch_synth5(args, batch, stream)
-	           : gvtm::launch_synth(args, batch, plan->precision, plan->generation, rows, stream);
+	           : gvtm::launch_synth(args, batch, plan->precision, rows, stream);
 	if (plan->timing) {
 		(void) hipEventRecord(ev.stop, stream);
 		plan->pending.push_back(ev);
@@ -553,15 +599,26 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 	if (batch == 0) return GVTM_OK;
 	if (!audio) return fail(GVTM_ERR_INVALID_ARGUMENT, "null audio buffer");
 	if (max_frames > 0 && !params) return fail(GVTM_ERR_INVALID_ARGUMENT, "null params with max_frames > 0");
-	if (frame_counts) {
-		for (size_t b = 0; b < batch; ++b) {
-			if (frame_counts[b] < 0 || static_cast<size_t>(frame_counts[b]) > max_frames) {
-				return fail(GVTM_ERR_INVALID_ARGUMENT, "frame_counts entry outside [0, max_frames]");
+	// A frame count outside [0, max_frames] fails THAT utterance (out_counts[b] = -1, no samples); the others are
+	// synthesized.  The device sees it as an empty utterance.
+	std::vector<int32_t> sane;
+	std::vector<size_t> bad;
+	try {
+		if (frame_counts) {
+			for (size_t b = 0; b < batch; ++b) {
+				if (frame_counts[b] < 0 || static_cast<size_t>(frame_counts[b]) > max_frames) {
+					if (sane.empty()) sane.assign(frame_counts, frame_counts + batch);
+					sane[b] = 0;
+					bad.push_back(b);
+				}
 			}
-			if (gvtm_output_count(plan, static_cast<size_t>(frame_counts[b])) == static_cast<size_t>(-1)) return GVTM_ERR_UNSUPPORTED;
 		}
+	} catch (const std::bad_alloc&) {
+		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
 	}
-	hipError_t e = hipSetDevice(plan->device);
+	const int32_t* const counts_in = sane.empty() ? frame_counts : sane.data();
+	DeviceScope scope(plan->device);
+	hipError_t e = scope.status();
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	const size_t pbytes = sizeof(float) * batch * max_frames * GVTM_N_PARAM;
 	const size_t abytes = sizeof(float) * batch * audio_stride;
@@ -569,9 +626,9 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 	if ((e = plan->s_audio.ensure(abytes ? abytes : 16)) != hipSuccess) return fail_hip(e, "hipMalloc audio");
 	if ((e = plan->s_counts.ensure(sizeof(int64_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc counts");
 	if ((e = plan->s_maxabs.ensure(sizeof(float) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc maxabs");
-	if (frame_counts && (e = plan->s_frames.ensure(sizeof(int32_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc frames");
+	if (counts_in && (e = plan->s_frames.ensure(sizeof(int32_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc frames");
 	if (pbytes && (e = hipMemcpy(plan->s_params.ptr, params, pbytes, hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "H2D params");
-	if (frame_counts && (e = hipMemcpy(plan->s_frames.ptr, frame_counts, sizeof(int32_t) * batch, hipMemcpyHostToDevice)) != hipSuccess) {
+	if (counts_in && (e = hipMemcpy(plan->s_frames.ptr, counts_in, sizeof(int32_t) * batch, hipMemcpyHostToDevice)) != hipSuccess) {
 		return fail_hip(e, "H2D frame_counts");
 	}
 	// Large batches go in slices: the kernels of all slices are queued on one stream, and each slice's samples are
@@ -580,10 +637,12 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 	// busy with the shape the whole batch would have used (1024 utterances = 256 workgroups of four).
 	constexpr size_t kSlice = 1024;
 	float* const d_params = static_cast<float*>(plan->s_params.ptr);
-	const int32_t* const d_frames = frame_counts ? static_cast<const int32_t*>(plan->s_frames.ptr) : nullptr;
+	const int32_t* const d_frames = counts_in ? static_cast<const int32_t*>(plan->s_frames.ptr) : nullptr;
 	float* const d_audio = static_cast<float*>(plan->s_audio.ptr);
 	int64_t* const d_counts = static_cast<int64_t*>(plan->s_counts.ptr);
 	float* const d_maxabs = static_cast<float*>(plan->s_maxabs.ptr);
+	// rows come back zero beyond their sample count (the staging buffer is reused between calls)
+	const bool ragged = counts_in != nullptr || audio_stride > gvtm_output_count(plan, max_frames);
 	if (batch >= 2 * kSlice) {
 		if (!plan->compute_stream && (e = hipStreamCreateWithFlags(&plan->compute_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
 		if (!plan->copy_stream && (e = hipStreamCreateWithFlags(&plan->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
@@ -596,6 +655,7 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 		const int saved_rows = plan->rows;
 		if (plan->rows == 0) plan->rows = gvtm::synth_rows(plan->precision, batch, 0, plan->design.k.section_delay); // the whole batch's shape
 		int rc = GVTM_OK;
+		if (ragged && (e = hipMemsetAsync(d_audio, 0, abytes, plan->compute_stream)) != hipSuccess) rc = fail_hip(e, "hipMemsetAsync");
 		for (size_t i = 0; i < n_slices && rc == GVTM_OK; ++i) {
 			const size_t lo = i * kSlice, n = std::min(kSlice, batch - lo);
 			rc = gvtm_synthesize_batch_device(plan, d_params + lo * max_frames * GVTM_N_PARAM, d_frames ? d_frames + lo : nullptr, n, max_frames,
@@ -618,6 +678,7 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 		if ((e = hipStreamSynchronize(plan->copy_stream)) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution / D2H audio");
 		if ((e = hipStreamSynchronize(plan->compute_stream)) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
 	} else {
+		if (ragged && (e = hipMemsetAsync(d_audio, 0, abytes, nullptr)) != hipSuccess) return fail_hip(e, "hipMemsetAsync");
 		const int rc = gvtm_synthesize_batch_device(plan, d_params, d_frames, batch, max_frames, d_audio, audio_stride, d_counts, d_maxabs, nullptr);
 		if (rc != GVTM_OK) return rc;
 		if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
@@ -629,6 +690,12 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 	if (maxabs && (e = hipMemcpy(maxabs, d_maxabs, sizeof(float) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
 		return fail_hip(e, "D2H maxabs");
 	}
+	for (size_t b : bad) {
+		if (out_counts) out_counts[b] = -1;
+		if (maxabs) maxabs[b] = 0.0f;
+		std::fill(audio + b * audio_stride, audio + (b + 1) * audio_stride, 0.0f);
+	}
+	if (!bad.empty()) g_last_error = "frame_counts entry outside [0, max_frames]: those utterances have out_counts = -1";
 	return GVTM_OK;
 }
 
@@ -644,7 +711,8 @@ int gvtm_normalize_batch_device(gvtm_plan* plan, const float* d_audio, size_t ba
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "exactly one of d_out_f32 / d_out_i16 must be given");
 	}
 	if (batch > 65535) return fail(GVTM_ERR_INVALID_ARGUMENT, "normalize: batch above 65535 per call");
-	hipError_t e = hipSetDevice(plan->device);
+	DeviceScope scope(plan->device);
+	hipError_t e = scope.status();
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
 	gvtm::NormalizeArgs args;
 	args.audio = d_audio;

@@ -1,7 +1,7 @@
 // Design-time math for the batched vocal-tract model (host; fp64, or float for GVTM_PRECISION_F32).
 //
 // Each routine states which reference routine defines the numbers it must
-// reproduce; tests/test_design_tables.py compares every table with the oracle
+// reproduce; tests/test_capi_cpu.py compares every table with the oracle
 // bit for bit through gvtm_plan_table().
 #include "vtm_design.hpp"
 
@@ -496,28 +496,6 @@ std::string design_plan5(const gvtm5_config& c, double control_rate, Design& out
 	out.fir.clear();
 	out.wavetable.clear();
 	return "";
-}
-
-bool output_count_for_steps(const DeviceConstants& k, uint64_t steps, uint64_t& n_out)
-{
-	// An output sample k is emitted while its integer read position
-	// P_k = floor(k * time_inc / 2^16) lies before the end pointer, and the final end pointer
-	// (after flushBuffer()'s 2*pad zero fills, SampleRateConverter.h:462-471) is steps + 2*pad.
-	const uint64_t fills = steps + 2ull * static_cast<uint64_t>(k.pad);
-	n_out = ((fills << 16) + k.time_inc - 1) / k.time_inc;
-	if (k.upsampling) return true;
-	// Down-sampling: the read position advances by more than one input sample per output, so
-	// an automatic dataEmpty() (every fill_size fills) can leave emptyPtr beyond its end
-	// pointer.  If fewer fills than that overshoot follow before flushBuffer()'s explicit
-	// dataEmpty(), it sees endPtr < emptyPtr, adds the ring size and converts ~1024 stale ring
-	// samples (SampleRateConverter.h:298-308).  That output depends on ring leftovers; it is
-	// detected here and refused rather than reproduced.
-	const uint64_t fill_size = static_cast<uint64_t>(kSrcRing - 2 * k.pad);
-	const uint64_t last_auto_end = (fills / fill_size) * fill_size;
-	if (last_auto_end == 0) return true;
-	const uint64_t k_star = ((last_auto_end << 16) + k.time_inc - 1) / k.time_inc; // first output at or past it
-	const uint64_t p_star = (k_star * static_cast<uint64_t>(k.time_inc)) >> 16;
-	return p_star <= fills;
 }
 
 // --- parameter-track generation (vtm_tracks.hip) -----------------------------------------------------

@@ -103,10 +103,53 @@ void radiation_impedance(double radius, double period, double out[6]);
 // Util::amplitude60dB (vtm/VTMUtil.h:48-67)
 double amplitude_60db(double db);
 
-// Output bookkeeping of SampleRateConverter for a track of `steps` internal samples:
-// number of samples after flushBuffer(); returns false when the reference's ring-wrap
-// defect would trigger (see DESIGN.md "SRC flush overrun").
-bool output_count_for_steps(const DeviceConstants& k, uint64_t steps, uint64_t& n_out);
+#if defined(__HIPCC__)
+#define GVTM_DESIGN_HD __host__ __device__ inline
+#else
+#define GVTM_DESIGN_HD inline
+#endif
+
+// Output bookkeeping of SampleRateConverter for a track of `steps` internal samples (host and device).
+//
+// Output sample k is emitted while its integer read position P_k = floor(k * time_inc / 2^16) lies before the end
+// pointer; the final end pointer (after flushBuffer()'s 2 * pad zero fills, SampleRateConverter.h:462-471) is
+// fills = steps + 2 * pad, so normally N = ceil(fills * 2^16 / time_inc) = k_from.
+//
+// The flush overrun (SampleRateConverter.h:298-308): when down-sampling the read position advances by more than one
+// input per output, so an automatic dataEmpty() (every fill_size = 1024 - 2 * pad fills) can leave the empty pointer
+// BEYOND its end pointer.  If fewer fills than that overshoot follow before flushBuffer()'s explicit dataEmpty(), it
+// finds endPtr < emptyPtr_, adds BUFFER_SIZE and converts one more lap of the ring: outputs [k_from, k_to) with read
+// positions up to fills + 1024, taken from the ring's leftovers.  Returns whether that happens.
+GVTM_DESIGN_HD bool src_flush_overrun(unsigned time_inc, int pad, uint64_t steps, uint64_t& k_from, uint64_t& k_to)
+{
+	const uint64_t fills = steps + 2ull * static_cast<uint64_t>(pad);
+	const uint64_t fill_size = static_cast<uint64_t>(kSrcRing - 2 * pad);
+	const uint64_t last_auto_end = (fills / fill_size) * fill_size; // end pointer of the last automatic dataEmpty()
+	k_from = ((fills << 16) + time_inc - 1) / time_inc;
+	k_to = k_from;
+	if (last_auto_end == 0) return false;
+	const uint64_t k_star = ((last_auto_end << 16) + time_inc - 1) / time_inc; // first output it did not emit
+	const uint64_t p_star = (k_star * static_cast<uint64_t>(time_inc)) >> 16; // where it left the empty pointer
+	if (p_star <= fills) return false;
+	k_to = (((fills + static_cast<uint64_t>(kSrcRing)) << 16) + time_inc - 1) / time_inc;
+	return true;
+}
+
+// samples in outputBuffer() after finishSynthesis()
+GVTM_DESIGN_HD uint64_t src_output_count(unsigned time_inc, int pad, int upsampling, uint64_t steps)
+{
+	uint64_t k_from = 0, k_to = 0;
+	if (upsampling) return (((steps + 2ull * static_cast<uint64_t>(pad)) << 16) + time_inc - 1) / time_inc;
+	return src_flush_overrun(time_inc, pad, steps, k_from, k_to) ? k_to : k_from;
+}
+
+// the largest src_output_count() over all tracks of at most `steps` internal samples: what a row of a ragged batch
+// must be able to hold (a shorter track that runs into the flush overrun can be LONGER than the longest track)
+inline uint64_t src_output_capacity(unsigned time_inc, int pad, int upsampling, uint64_t steps)
+{
+	const uint64_t lap = upsampling ? 0ull : static_cast<uint64_t>(kSrcRing);
+	return (((steps + 2ull * static_cast<uint64_t>(pad) + lap) << 16) + time_inc - 1) / time_inc;
+}
 
 // --- parameter-track generation (vtm_tracks.hip) ---
 

@@ -1,31 +1,13 @@
 // CDNA4 (gfx950) kernels of the batched vocal-tract model.
 //
-// One workgroup (256 threads = 4 wavefronts) owns one utterance and walks it in
-// chunks of kChunk internal-rate steps.  Inside a chunk the reference's per-sample
-// object graph (VocalTractModel0::execSynthesisStep, vtm/VocalTractModel0.h:396-445)
-// is re-cut by *dependency structure* instead of by class:
+//   vtm_synth_kernel   (vtm_kernel_v2.inc)  VocalTractModel0 / 2 / 4 semantics: a workgroup owns 1, 2, 4 or 8 utterances and
+//                      5 + NH wavefronts with fixed roles (tube, scans, pre-/post-tube filters, interpolation, helpers),
+//                      software-pipelined over chunks of internal-rate steps with one barrier per tick; see that file's header
+//   vtm5_synth_kernel  (vtm_kernel_m5.inc)  VocalTractModel5 semantics, same organisation
+//   vtm_normalize_kernel                    output scaling of Controller::writeOutputToBuffer / writeOutputToFile
 //
-//   P1  interpolate   16 lanes, one per parameter: the float32 running sum of
-//                     Controller::synthesize (vtm_control_model/Controller.cpp:294-311)
-//   P2  convert       one lane per step: pitch->phase increment, dB->amplitude,
-//                     radii->junction coefficients, frication taps, band-pass design
-//                     (VocalTractModel0.h:399-404, :484-552; BandpassFilter.h:91-110)
-//   P3  scan          one lane: the two truly serial scalar recurrences, oscillator
-//                     phase (WavetableGlottalSource.h:196-199, :265-272) and the noise
-//                     generator (NoiseSource.h:40-44, NoiseFilter.h:63-68)
-//   P4  source        one lane per half-step wavetable lookup, then one lane per step:
-//                     49-tap FIR, breathiness / cross-mix (WavetableGlottalSource.h:212-235,
-//                     WavetableGlottalSourceFIRFilter.h:276-304, VocalTractModel0.h:416-438)
-//   P5  tube          one wavefront, ONE LANE PER TUBE SECTION (10 oropharynx + 6 nasal =
-//                     one 16-lane DPP row): scattering junctions with row_shr/row_shl
-//                     neighbour exchange, mouth/nose reflection+radiation filters on the
-//                     two end lanes, band-pass and throat IIRs (VocalTractModel0.h:565-661)
-//   P6  resample      one lane per OUTPUT sample: the Kaiser-sinc polyphase converter
-//                     evaluated feed-forward from the 16.16 time register
-//                     (SampleRateConverter.h:295-416), coalesced float32 stores
-//
-// Everything between the parameter frames (HBM in) and the audio samples (HBM out)
-// lives in LDS; there is no intermediate global traffic.
+// Everything between the parameter frames (HBM in) and the audio samples (HBM out) lives in LDS; there is no
+// intermediate global traffic.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -40,7 +22,6 @@ namespace {
 #include "vtm_device_common.inc"
 } // namespace
 
-#include "vtm_kernel_v1.inc"
 #include "vtm_kernel_v2.inc"
 #include "vtm_kernel_m5.inc"
 
@@ -64,18 +45,7 @@ __global__ __launch_bounds__(256) void vtm_normalize_kernel(const NormalizeArgs 
 	}
 }
 
-template <typename TT, typename ST, int D>
-static hipError_t launch_v1(const SynthArgs& args, size_t batch, size_t lds, hipStream_t stream)
-{
-	auto fn = v1::vtm_synth_kernel<TT, ST, D>;
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-			static_cast<int>(lds));
-	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(batch)), dim3(kBlock), lds, stream, args);
-	return hipGetLastError();
-}
-
-// generation-2 geometry: utterances per workgroup (DPP rows), chunk length, helper wavefronts,
+// kernel geometry: utterances per workgroup (DPP rows), chunk length, helper wavefronts,
 // internal-rate ring length
 template <typename CT, typename ST, int U_, int D_ = 1>
 struct V2Shape {
@@ -111,9 +81,18 @@ struct V2Shape {
 	// 8 resp. 12 wavefronts per workgroup; eight rows: two wavefronts per serial role + 6 helpers = 16
 	static constexpr int NH = (U_ == 1) ? GVTM_TUNE_NH_SINGLE : (U_ == 8 ? GVTM_TUNE_NH_OCTO : GVTM_TUNE_NH_MULTI);
 	static constexpr int kWaves = 5 * ((U_ + 3) / 4) + NH;
-	// internal-rate ring: two chunks + resampler history + flush zeros, a power of two
-	static constexpr int XR = (2 * C + 4 * kMaxPad <= 512) ? 512 : 1024;
 };
+
+// internal-rate ring of a workgroup row: a power of two holding two chunks, the resampler's history and the
+// flush zeros; the reference's own BUFFER_SIZE when down-sampling (the flush overrun reads the ring's leftovers
+// modulo that length, vtm_kernel_v2.inc's epilogue)
+static int ring_length(const DeviceConstants& k, int chunk)
+{
+	if (!k.upsampling) return kSrcRing;
+	int xr = 128;
+	while (xr < 2 * chunk + 4 * k.pad) xr *= 2;
+	return xr;
+}
 
 // helper wavefronts of the 48-section tube's workgroups: U tube wavefronts + 4 other serial ones + helpers = 12
 // (three wavefronts per SIMD: 168 registers each)
@@ -135,8 +114,9 @@ static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t str
 	using S = V2Shape<CT, ST, U, D>;
 	constexpr int NH = LAYOUT == 1 ? wide_helpers<U>() : S::NH;
 	constexpr int kWaves = v2::serial_waves<U, LAYOUT>() + NH;
-	auto fn = v2::vtm_synth_kernel<CT, ST, D, S::U, S::C, NH, S::XR, LAYOUT>;
-	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C, S::XR>();
+	auto fn = v2::vtm_synth_kernel<CT, ST, D, S::U, S::C, NH, LAYOUT>;
+	if (args.xr != ring_length(args.k, S::C) || 2 * S::C + 4 * args.k.pad > args.xr) return hipErrorInvalidValue;
+	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C>(args.xr);
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
 	if (e != hipSuccess) return e;
@@ -170,28 +150,41 @@ int synth_rows(int precision, size_t batch, int requested, int section_delay)
 	return rows > max_rows ? max_rows : rows;
 }
 
+// what depends on the workgroup shape V2Shape picks: chunk length -> ring length -> LDS bytes
+struct ShapeNumbers { int chunk; size_t lds_fixed; size_t ring_elem; };
+
 template <typename CT, typename ST, int U>
-static size_t v2_lds()
+static ShapeNumbers v2_numbers()
 {
 	using S = V2Shape<CT, ST, U>;
-	return v2::smem_bytes<CT, ST, S::U, S::C, S::XR>();
+	return ShapeNumbers{S::C, v2::smem_bytes<CT, ST, S::U, S::C>(0), sizeof(ST) * S::U};
 }
 
 template <typename CT, typename ST>
-static size_t v2_lds_rows(int rows)
+static ShapeNumbers v2_numbers_rows(int rows)
 {
 	if constexpr (sizeof(CT) == 4) {
-		if (rows == 8) return v2_lds<CT, ST, 8>();
+		if (rows == 8) return v2_numbers<CT, ST, 8>();
 	}
-	return rows == 4 ? v2_lds<CT, ST, 4>() : (rows == 2 ? v2_lds<CT, ST, 2>() : v2_lds<CT, ST, 1>());
+	return rows == 4 ? v2_numbers<CT, ST, 4>() : (rows == 2 ? v2_numbers<CT, ST, 2>() : v2_numbers<CT, ST, 1>());
 }
 
-size_t synth_lds_bytes(int precision, int generation, int rows)
+static ShapeNumbers shape_numbers(int precision, int rows)
 {
-	if (generation == 1) return v1::synth_lds_bytes(precision == GVTM_PRECISION_MIXED);
-	if (precision == GVTM_PRECISION_F32) return v2_lds_rows<float, float>(rows);
-	if (precision == GVTM_PRECISION_MIXED) return v2_lds_rows<double, float>(rows);
-	return v2_lds_rows<double, double>(rows);
+	if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float>(rows);
+	if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float>(rows);
+	return v2_numbers_rows<double, double>(rows);
+}
+
+int synth_ring_length(const DeviceConstants& k, int precision, int rows)
+{
+	return ring_length(k, shape_numbers(precision, rows).chunk);
+}
+
+size_t synth_lds_bytes(const DeviceConstants& k, int precision, int rows)
+{
+	const ShapeNumbers n = shape_numbers(precision, rows);
+	return n.lds_fixed + ((n.ring_elem * static_cast<size_t>(ring_length(k, n.chunk)) + 15) & ~size_t(15));
 }
 
 template <typename CT, typename ST, int U>
@@ -224,37 +217,15 @@ static hipError_t launch_v2_rows(const SynthArgs& args, size_t batch, int rows, 
 	return launch_v2_d<CT, ST, 1>(args, batch, stream);
 }
 
-hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int generation, int rows, hipStream_t stream)
+hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int rows, hipStream_t stream)
 {
-	const int d = args.k.section_delay;
-	const bool mixed = precision == GVTM_PRECISION_MIXED;
-	if (generation == 1) {
-		if (precision == GVTM_PRECISION_F32) return hipErrorInvalidValue; // the round-1 baseline kernel is fp64 / mixed only
-		const size_t lds = v1::synth_lds_bytes(mixed);
-		if (mixed) {
-			switch (d) {
-			case 1: return launch_v1<double, float, 1>(args, batch, lds, stream);
-			case 2: return launch_v1<double, float, 2>(args, batch, lds, stream);
-			case 3: return launch_v1<double, float, 3>(args, batch, lds, stream);
-			case 4: return launch_v1<double, float, 4>(args, batch, lds, stream);
-			}
-		} else {
-			switch (d) {
-			case 1: return launch_v1<double, double, 1>(args, batch, lds, stream);
-			case 2: return launch_v1<double, double, 2>(args, batch, lds, stream);
-			case 3: return launch_v1<double, double, 3>(args, batch, lds, stream);
-			case 4: return launch_v1<double, double, 4>(args, batch, lds, stream);
-			}
-		}
-		return hipErrorInvalidValue;
-	}
 	if (precision == GVTM_PRECISION_F32) return launch_v2_rows<float, float>(args, batch, rows, stream);
-	if (mixed) return launch_v2_rows<double, float>(args, batch, rows, stream);
+	if (precision == GVTM_PRECISION_MIXED) return launch_v2_rows<double, float>(args, batch, rows, stream);
 	return launch_v2_rows<double, double>(args, batch, rows, stream);
 }
 
 // reference model 5: chunk of 60 steps (one 64-lane pass per per-step stage), three helper wavefronts
-constexpr int kM5Chunk = 60, kM5Helpers = 3, kM5Ring = 512;
+constexpr int kM5Chunk = 60, kM5Helpers = 3, kM5Ring = kSrcRing; // the reference's BUFFER_SIZE: see the flush-overrun epilogue
 
 size_t synth5_lds_bytes()
 {

@@ -10,13 +10,9 @@
 
 namespace gvtm {
 
-constexpr int kBlock = 256;  // threads per workgroup (4 wavefronts)
-constexpr int kChunk = 192;  // internal-rate steps per chunk; multiple of every supported SectionDelay
-constexpr int kXCap = (2 * kMaxPad) + kChunk + (2 * kMaxPad); // SRC window: history + chunk + flush zeros
-
 struct SynthArgs {
-	DeviceConstants k;              // by value (generation 1)
-	const DeviceConstants* kconst;  // the same constants in device memory (generation 2 stages them in LDS)
+	DeviceConstants k;              // by value (host-side launch decisions)
+	const DeviceConstants* kconst;  // the same constants in device memory (the kernel stages them in LDS)
 	const float* params;         // [batch][max_frames][16]
 	const int32_t* frame_counts; // [batch] or null
 	float* audio;                // [batch][audio_stride]
@@ -29,8 +25,9 @@ struct SynthArgs {
 	size_t max_frames;
 	size_t audio_stride;
 	size_t batch;
+	int xr;                      // internal-rate ring length per utterance (a power of two; synth_ring_length())
 	double* debug_taps;          // null, or [batch][max_frames*control_steps][8] per-step taps (tests only)
-	unsigned long long* phase_cycles; // null, or [batch][8] shader cycles spent per phase (diagnostics only)
+	unsigned long long* phase_cycles; // null, or [workgroups][16] shader cycles per role wavefront and helper stage (diagnostics only)
 	const Model5Constants* k5const = nullptr; // model 5 only: its constants in device memory
 };
 
@@ -44,13 +41,15 @@ struct NormalizeArgs {
 	size_t audio_stride;
 };
 
-// generation: 1 = phase-alternating baseline, 2 = wave-specialised pipeline (default)
-// rows: utterances per workgroup for generation 2 (1, 2 or 4); synth_rows() picks it from the
-// batch size unless `requested` names one
-// precision: gvtm_precision (GVTM_PRECISION_F32 runs on generation 2 only)
+// rows: utterances per workgroup (1, 2, 4 or 8); synth_rows() picks it from the batch size unless `requested` names one
+// precision: gvtm_precision
 int synth_rows(int precision, size_t batch, int requested, int section_delay = 1);
-size_t synth_lds_bytes(int precision, int generation, int rows);
-hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int generation, int rows, hipStream_t stream);
+// internal-rate ring length for a plan: the reference's BUFFER_SIZE (1024) when down-sampling, so that the flush
+// overrun aliases as the reference's ring does; otherwise the smallest power of two holding two chunks, the
+// resampler's history and the flush zeros
+int synth_ring_length(const DeviceConstants& k, int precision, int rows);
+size_t synth_lds_bytes(const DeviceConstants& k, int precision, int rows);
+hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int rows, hipStream_t stream);
 // reference model 5 (VocalTractModel5<double,1>): one utterance per workgroup, fp64
 size_t synth5_lds_bytes();
 hipError_t launch_synth5(const SynthArgs& args, size_t batch, hipStream_t stream);

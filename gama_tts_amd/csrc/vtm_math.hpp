@@ -14,7 +14,7 @@
 #include <cstdint>
 #include <cstring>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define GVTM_HD __host__ __device__ __forceinline__
 #else
 #define GVTM_HD inline

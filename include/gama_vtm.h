@@ -51,7 +51,8 @@ typedef enum gvtm_status {
 	GVTM_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad size, bad configuration value */
 	GVTM_ERR_NO_DEVICE = 2,        /* no HIP device / device index out of range */
 	GVTM_ERR_HIP = 3,              /* a HIP runtime call failed (see gvtm_last_error) */
-	GVTM_ERR_UNSUPPORTED = 4,      /* valid for the reference but not implemented on the device */
+	GVTM_ERR_UNSUPPORTED = 4,      /* valid for the reference but not implemented on the device (e.g. interactive
+	                                  streams of reference model 5) */
 	GVTM_ERR_OUT_OF_MEMORY = 5
 } gvtm_status;
 
@@ -191,17 +192,25 @@ int gvtm_plan_info(const gvtm_plan* plan, gvtm_info* info_out);
 /* Copies a design table into out[capacity]; returns the element count or a negative status. */
 int gvtm_plan_table(const gvtm_plan* plan, int which, double* out, size_t capacity);
 
-/* Samples finishSynthesis() leaves for an utterance of n_frames frames; (size_t)-1 when the
- * frame count is not representable (see GVTM_ERR_UNSUPPORTED in DESIGN.md). */
+/* Samples finishSynthesis() leaves for an utterance of n_frames frames; (size_t)-1 for a null plan.  Includes the
+ * reference converter's flush overrun (vtm/SampleRateConverter.h:298-308 with :462-471): on down-sampling plans
+ * (reference models 3, 4, 5 at 44.1 / 48 kHz) about 0.4 % of the frame counts make flushBuffer()'s final dataEmpty()
+ * convert one more lap of the 1024-sample ring (~750 extra samples computed from ring leftovers); the device
+ * reproduces those samples, so such a count is LARGER than that of the next longer utterance. */
 size_t gvtm_output_count(const gvtm_plan* plan, size_t n_frames);
+/* max over n <= max_frames of gvtm_output_count(plan, n): the audio_stride that holds every utterance of a ragged
+ * batch.  Equal to gvtm_output_count(plan, max_frames) on up-sampling plans. */
+size_t gvtm_output_capacity(const gvtm_plan* plan, size_t max_frames);
 
 /*
  * Batch synthesis, everything resident in device memory.
  *   d_params       [batch][max_frames][16] float32, reference frame order
  *   d_frame_counts [batch] int32 frames per utterance (<= max_frames), or NULL: all max_frames
  *   d_audio        [batch][audio_stride] float32, unscaled samples as in outputBuffer();
- *                  audio_stride >= gvtm_output_count(plan, max_frames)
- *   d_out_counts   [batch] int64 samples written per utterance, may be NULL
+ *                  audio_stride >= gvtm_output_count(plan, max_frames) is required, gvtm_output_capacity(plan,
+ *                  max_frames) holds every utterance of a ragged batch (samples beyond audio_stride are dropped,
+ *                  d_out_counts still reports them); [count, audio_stride) of a row is left untouched
+ *   d_out_counts   [batch] int64 samples per utterance, may be NULL
  *   d_maxabs       [batch] float32 max|x| per utterance, may be NULL
  *   hip_stream     hipStream_t (NULL = default stream); the call only enqueues work
  */
@@ -209,7 +218,10 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 		size_t batch, size_t max_frames, float* d_audio, size_t audio_stride,
 		int64_t* d_out_counts, float* d_maxabs, void* hip_stream);
 
-/* Same with host buffers (H2D, kernel, D2H, synchronous).  frame_counts may be NULL. */
+/* Same with host buffers (H2D, kernel, D2H, synchronous).  frame_counts may be NULL.  A frame_counts[b] outside
+ * [0, max_frames] fails that utterance only: out_counts[b] = -1, its row zeroed, the call still returns GVTM_OK
+ * (gvtm_last_error() names the cause).  Rows are zero beyond their sample count.  The caller's current HIP device
+ * is restored before returning (every entry point does). */
 int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
 		size_t batch, size_t max_frames, float* audio, size_t audio_stride,
 		int64_t* out_counts, float* maxabs);

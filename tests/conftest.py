@@ -38,3 +38,12 @@ def golden_tracks():
     """Captured EventList::generateOutput() calls of the reference (tests/golden/make_tracks_golden.py)."""
     z = np.load(os.path.join(HERE, "golden", "tracks_golden.npz"), allow_pickle=False)
     return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden_overrun():
+    """Reference vectors at flush-overrun lengths of the sample-rate converter (tests/golden/make_overrun_golden.py)."""
+    z = np.load(os.path.join(HERE, "golden", "vtm_overrun_golden.npz"), allow_pickle=False)
+    data = {k: z[k] for k in z.files}
+    data["manifest"] = json.loads(bytes(data.pop("manifest_json")).decode())
+    return data

@@ -111,3 +111,33 @@ CASES = [
 ]
 
 DIGEST_STRIDE = 97
+
+# Lengths at which the reference's SampleRateConverter runs into its flush overrun (SampleRateConverter.h:298-308 with
+# :462-471: the final dataEmpty() finds endPtr < emptyPtr_, adds BUFFER_SIZE and converts one more lap of the ring from
+# its leftovers).  Own file (tests/golden/vtm_overrun_golden.npz, made by tests/golden/make_overrun_golden.py from the
+# REAL reference); "tail" = SHA-256 of everything + a strided subset + the last OVERRUN_TAIL samples (the extra lap and
+# what precedes it).  model5 = True: the 5_male voice / VocalTractModel5.
+OVERRUN_TAIL = 1600
+
+
+def O(name, frames, seed, model, delay=1, rate=44100.0, layout=0, fm=0, model5=False, store="tail"):
+    c = C(name, ("random", frames, seed, True), model=model, delay=delay, rate=rate, store=store, layout=layout, fm=fm)
+    c["model5"] = model5
+    return c
+
+
+OVERRUN_CASES = [
+    O("ovr_d2_22k_18f", 18, 31, "2:2", delay=2, rate=22050.0, store="full"),
+    O("ovr_d2_22k_79f_float", 79, 32, "2f:2", delay=2, rate=22050.0, fm=1, store="full"),
+    O("ovr_m3_22k_83f", 83, 33, "3", delay=3, rate=22050.0, store="full"),
+    O("ovr_m4_22k_83f", 83, 34, "4", layout=1, rate=22050.0, store="full"),
+    O("ovr_m4f_22k_202f", 202, 35, "4f", layout=1, rate=22050.0, fm=1),
+    # the shipped voices' own rate class: models 3 / 4 at 44.1 kHz overrun at 2334, 2581, 2828 frames
+    O("ovr_m3_44k_2334f", 2334, 36, "3", delay=3),
+    O("ovr_m4_44k_2334f", 2334, 37, "4", layout=1),
+    O("ovr_m3f_44k_2581f", 2581, 38, "2f:3", delay=3, fm=1),
+    O("ovr_m4f_44k_2828f", 2828, 39, "4f", layout=1, fm=1),
+    # model 5 (5_male voice) at 44.1 kHz: 106 frames; at 22.05 kHz: 696
+    O("ovr_m5_44k_106f", 106, 40, "5", model5=True, store="full"),
+    O("ovr_m5_22k_696f", 696, 41, "5", rate=22050.0, model5=True),
+]

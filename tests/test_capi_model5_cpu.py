@@ -56,21 +56,19 @@ def test_rejections_and_no_cpu_path():
 
 
 def test_output_counts_follow_the_reference_converter():
-    """Every frame count either gives the oracle's (= the reference converter's) sample count, or is refused because the
-    reference would convert a ring of stale samples there (SampleRateConverter's flush overrun)."""
+    """Every frame count gives the oracle's (= the reference converter's) sample count, the two lengths at which the
+    reference converts a ring of stale samples more included (SampleRateConverter's flush overrun)."""
     d = g.read_config_file(oracle.VOICE5_MALE)
-    refused = 0
+    overruns = 0
     for rate, frames in ((44100.0, list(range(0, 120, 7)) + [105, 106, 107]), (22050.0, [1, 50, 695, 696, 697]), (48000.0, [0, 1, 2, 3, 100])):
         plan = g.Plan(g.config5_from_dict(d, rate), 250.0, capi.DEVICE_NONE)
         cfg = oracle.male5_config(rate)
         ratio = rate / plan.info.internal_rate_hz
         for f in frames:
             want = oracle.synthesize5(cfg, np.zeros((f, 16), np.float32))[0].size
-            try:
-                assert plan.output_count(f) == want, (rate, f)
-            except g.GvtmError as e:
-                assert e.status == 4  # GVTM_ERR_UNSUPPORTED
-                refused += 1
-                closed = (f * plan.info.control_steps + 2 * plan.info.pad_size) * ratio
+            assert plan.output_count(f) == want, (rate, f)
+            closed = (f * plan.info.control_steps + 2 * plan.info.pad_size) * ratio
+            if want - closed > 2:
+                overruns += 1
                 assert abs((want - closed) / ratio - 1024) < 16, (rate, f, want, closed)  # one ring of stale input more
-    assert refused == 2  # 106 frames at 44.1 kHz, 696 at 22.05 kHz
+    assert overruns == 2  # 106 frames at 44.1 kHz, 696 at 22.05 kHz

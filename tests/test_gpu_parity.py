@@ -25,10 +25,11 @@ TOL_F64 = 1e-9
 TOL_MIXED = 1e-5
 
 
-def _plan(case_overrides=None, rate=44100.0, delay=1, crate=250.0, precision=capi.PRECISION_F64, layout=0):
+def _plan(case_overrides=None, rate=44100.0, delay=1, crate=250.0, precision=capi.PRECISION_F64, layout=0, rows=0):
+    """rows != 0: a plan of the diagnostics library (same kernels) with that many utterances per workgroup forced."""
     d = g.read_config_file(oracle.VOICE_MALE)
     d.update({k: str(v) for k, v in (case_overrides or {}).items()})
-    return g.Plan(g.config_from_dict(d, rate, delay, precision, layout), crate, 0)
+    return g.Plan(g.config_from_dict(d, rate, delay, precision, layout), crate, 0, diagnostics=bool(rows), rows=rows)
 
 
 def _within(got, ref, tol, peak=None):
@@ -152,13 +153,12 @@ def test_full_size_properties_config2():
 @pytest.mark.parametrize("rows,precision,tol", [(2, capi.PRECISION_F64, TOL_F64), (4, capi.PRECISION_F64, TOL_F64),
                                                   (2, capi.PRECISION_MIXED, TOL_MIXED), (4, capi.PRECISION_MIXED, TOL_MIXED)])
 @pytest.mark.parametrize("delay", [1, 3])
-def test_multi_row_workgroups(rows, precision, tol, delay, monkeypatch):
+def test_multi_row_workgroups(rows, precision, tol, delay):
     """Several utterances per workgroup (one DPP row each in the serial wavefronts), ragged
     lengths, a batch that does not fill the last workgroup."""
-    monkeypatch.setenv("GVTM_ROWS", str(rows))
     frames = np.array([40, 0, 17, 33, 40, 1, 25, 40, 8, 39, 40], dtype=np.int32)
     params = tracks.random_tracks(len(frames), 40, seed0=900 + rows, consonant_heavy=True)
-    plan = _plan(delay=delay, precision=precision)
+    plan = _plan(delay=delay, precision=precision, rows=rows)
     audio, counts, maxabs = plan.synthesize_host(params, frames)
     cfg = oracle.male_config(44100.0, delay)
     for b, f in enumerate(frames):
@@ -239,12 +239,11 @@ def test_special_case_frames(delay, layout):
 
 
 @pytest.mark.parametrize("precision,rows", [(capi.PRECISION_F64, 2), (capi.PRECISION_MIXED, 4), (capi.PRECISION_MIXED, 2)], ids=["f64x2", "mixedx4", "mixedx2"])
-def test_samples_do_not_depend_on_the_row_in_the_workgroup(precision, rows, monkeypatch):
-    """Several utterances per workgroup (GVTM_ROWS forces the shape a big batch would get): the same track must give the
-    same samples, bit for bit, in whichever DPP row and workgroup it lands (the resampler's per-row code is unrolled)."""
-    monkeypatch.setenv("GVTM_ROWS", str(rows))
-    plan = _plan(delay=2, precision=precision)
-    monkeypatch.delenv("GVTM_ROWS")
+def test_samples_do_not_depend_on_the_row_in_the_workgroup(precision, rows):
+    """Several utterances per workgroup (the shape a big batch would get, forced through the diagnostics library): the same
+    track must give the same samples, bit for bit, in whichever DPP row and workgroup it lands (the resampler's per-row
+    code is unrolled)."""
+    plan = _plan(delay=2, precision=precision, rows=rows)
     pool = tracks.random_tracks(3, 60, seed0=8100, consonant_heavy=True)
     order = [0, 1, 2, 2, 0, 1, 1, 2, 0, 0, 0]  # every track in several rows and workgroups
     audio, counts, _ = plan.synthesize_host(pool[order])

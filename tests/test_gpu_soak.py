@@ -1,0 +1,22 @@
+"""Reduced soak (tests/tools/soak.py is the large form): a ragged batch per model / precision in ONE launch each against
+the oracle, with utterances at the lengths where the reference's sample-rate converter runs into its flush overrun
+(SampleRateConverter.h:298-308 with :462-471) — no frame count is lowered or refused."""
+import pytest
+
+import soak_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reduced_soak_every_model():
+    res = soak_cases.run(batch=96, max_frames=120, workers=8)
+    assert set(res) == {c[0] for c in soak_cases.CASES} | {"model5_double"}
+    for name, s in res.items():
+        assert s["wrong_counts"] == 0, (name, s)
+        assert s["pass"], (name, s)
+        assert s["frame_counts_lowered"] == 0
+    # the down-sampling cases really contained overrun lengths
+    for name in ("model2f_d3_float_48k", "model4f_float", "model3_double", "model4_double_22k", "model5_double"):
+        assert res[name]["flush_overrun_utterances"] >= 1, (name, res[name])
+    for name in ("model1_float", "model2f_d2_float", "model2f_d3_float_48k", "model4f_float"):
+        assert res[name]["bit_identical_utterances"] == res[name]["utterances"], (name, res[name])

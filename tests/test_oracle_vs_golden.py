@@ -98,3 +98,44 @@ def test_noise_sequence_is_utterance_independent():
         w = seed - 0.5
         assert buf[i] == w + x1
         x1 = w
+
+
+def _overrun_oracle(case):
+    tr = golden_cases.track_for(case)
+    if case["model5"]:
+        cfg = oracle.male5_config(case["rate"])
+        return tr, oracle.synthesize5(cfg, tr)[0]
+    cfg = oracle.config_from_dict(oracle.read_config_file(oracle.VOICE_MALE), case["rate"], case["delay"], case.get("layout", 0),
+                                  case.get("float_model", 0))
+    return tr, oracle.synthesize(cfg, tr, case["crate"])
+
+
+@pytest.mark.parametrize("case", golden_cases.OVERRUN_CASES, ids=lambda c: c["name"])
+def test_oracle_matches_reference_at_flush_overrun_lengths(case, golden_overrun):
+    """The reference's SampleRateConverter converts one more lap of its ring at these lengths
+    (SampleRateConverter.h:298-308 with :462-471); the oracle walks the ring literally and must give the same bytes."""
+    m = golden_overrun["manifest"][case["name"]]
+    tr, out = _overrun_oracle(case)
+    assert out.size == m["n"]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == m["sha256"]
+    # the sample count really is the overrun's: one ring (1024 input samples) more than the closed form, and the
+    # product's count function (no GPU needed) agrees
+    import gama_tts_amd as g
+    from gama_tts_amd import capi
+    if case["model5"]:
+        plan = g.Plan(g.config5_from_dict(g.read_config_file(oracle.VOICE5_MALE), case["rate"]), case["crate"], capi.DEVICE_NONE)
+    else:
+        plan = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE), case["rate"], case["delay"],
+                                         capi.PRECISION_F32 if case["float_model"] else capi.PRECISION_F64, case.get("layout", 0)),
+                      case["crate"], capi.DEVICE_NONE)
+    i = plan.info
+    fills = tr.shape[0] * i.control_steps + 2 * i.pad_size
+    closed = -((-(fills << 16)) // i.time_register_increment)
+    lap = -((-((fills + 1024) << 16)) // i.time_register_increment)
+    assert plan.output_count(tr.shape[0]) == m["n"] == lap > closed
+    if case["store"] == "full":
+        assert np.array_equal(out, golden_overrun[case["name"] + "__out"])
+    else:
+        assert np.array_equal(out[:: golden_cases.DIGEST_STRIDE], golden_overrun[case["name"] + "__strided"])
+        assert np.array_equal(out[-golden_cases.OVERRUN_TAIL:], golden_overrun[case["name"] + "__tail"])
+        assert np.abs(out[-600:]).max() > 0  # the extra lap is not silence

@@ -18,14 +18,14 @@ prec = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 layout = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 params = tracks.random_tracks(2, frames, seed0=42, consonant_heavy=True)
 cfgd = g.read_config_file(oracle.VOICE_MALE)
-plan = g.Plan(g.config_from_dict(cfgd, 44100.0, delay, prec, layout), 250.0, 0)
+plan = g.Plan(g.config_from_dict(cfgd, 44100.0, delay, prec, layout), 250.0, 0, diagnostics=True)
 steps = frames * plan.info.control_steps
 n = plan.output_count(frames)
 dev = torch.device("cuda:0")
 d_params = torch.from_numpy(params).to(dev)
 d_audio = torch.zeros((2, n), dtype=torch.float32, device=dev)
 d_taps = torch.zeros((2, steps, 8), dtype=torch.float64, device=dev)
-lib = g.load_library()
+lib = g.load_library(diagnostics=True)
 lib.gvtm_debug_set_taps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.gvtm_debug_set_taps(plan._h, ctypes.c_void_p(d_taps.data_ptr()))
 plan.synthesize_device(d_params, 2, frames, d_audio, n)

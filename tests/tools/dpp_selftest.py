@@ -4,8 +4,8 @@ import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import gama_tts_amd as g
 import oracle
-plan = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE)), 250.0, 0)
-lib = g.load_library()
+plan = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE)), 250.0, 0, diagnostics=True)
+lib = g.load_library(diagnostics=True)
 out = np.zeros(640, dtype=np.int32)
 lib.gvtm_debug_dpp_selftest.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 rc = lib.gvtm_debug_dpp_selftest(plan._h, out.ctypes.data)

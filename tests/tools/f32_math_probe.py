@@ -6,8 +6,8 @@ import gama_tts_amd as g
 from gama_tts_amd import capi
 import oracle
 
-plan = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE), precision=capi.PRECISION_F32), 250.0, 0)
-lib = g.load_library()
+plan = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE), precision=capi.PRECISION_F32), 250.0, 0, diagnostics=True)
+lib = g.load_library(diagnostics=True)
 lib.gvtm_debug_device_float_math.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
 ol = oracle.lib()
 ol.vtmo_libm_powf.argtypes = [ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]

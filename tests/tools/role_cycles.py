@@ -18,13 +18,13 @@ delay = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 pool = tracks.random_tracks(min(batch, 64), frames, seed0=1000)
 params = np.concatenate([pool] * ((batch + len(pool) - 1) // len(pool)))[:batch]
 cfgd = g.read_config_file(oracle.VOICE_MALE)
-plan = g.Plan(g.config_from_dict(cfgd, 44100.0, delay, prec), 250.0, 0)
+plan = g.Plan(g.config_from_dict(cfgd, 44100.0, delay, prec), 250.0, 0, diagnostics=True)
 n = plan.output_count(frames)
 dev = torch.device("cuda:0")
 d_params = torch.from_numpy(params).to(dev)
 d_audio = torch.zeros((batch, n), dtype=torch.float32, device=dev)
 d_cyc = torch.zeros((batch, 16), dtype=torch.int64, device=dev)
-lib = g.load_library()
+lib = g.load_library(diagnostics=True)
 lib.gvtm_debug_set_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 for rep in range(2):
     lib.gvtm_debug_set_phase_cycles(plan._h, ctypes.c_void_p(d_cyc.data_ptr()))

@@ -15,13 +15,13 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 pool = tracks.random_tracks(min(batch, 64), frames, seed0=1000, consonant_heavy=True)
 params = np.concatenate([pool] * ((batch + len(pool) - 1) // len(pool)))[:batch]
-plan = g.Plan(g.config5_from_dict(g.read_config_file(oracle.VOICE5_MALE)), 250.0, 0)
+plan = g.Plan(g.config5_from_dict(g.read_config_file(oracle.VOICE5_MALE)), 250.0, 0, diagnostics=True)
 n = plan.output_count(frames)
 dev = torch.device("cuda:0")
 d_params = torch.from_numpy(params).to(dev)
 d_audio = torch.zeros((batch, n), dtype=torch.float32, device=dev)
 d_cyc = torch.zeros((batch, 16), dtype=torch.int64, device=dev)
-lib = g.load_library()
+lib = g.load_library(diagnostics=True)
 lib.gvtm_debug_set_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 for rep in range(2):
     lib.gvtm_debug_set_phase_cycles(plan._h, ctypes.c_void_p(d_cyc.data_ptr()))

@@ -4,9 +4,7 @@ batch, prec = sys.argv[1], sys.argv[2]
 variants = sys.argv[3:]
 for v in variants:
     env = dict(os.environ)
-    if v.startswith("rows"):
-        env["GVTM_ROWS"] = v[4:]
-    elif v != "default":
+    if v != "default":
         env["GVTM_LIBRARY"] = os.path.join("gama_tts_amd", "lib_variants", "libgama_vtm_%s.so" % v)
     r = subprocess.run([sys.executable, "bench.py", "--precision", prec, "--batch", batch, "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
                        capture_output=True, text=True, env=env)
