@@ -8,6 +8,7 @@ raises when the native library is missing.
 from .capi import (  # noqa: F401
     GvtmError,
     Plan,
+    Stream,
     TrackConfig,
     config5_from_dict,
     config_from_dict,

@@ -152,6 +152,18 @@ def load_library(diagnostics=False):
     L.gvtm_generate_tracks_device.restype = i32
     L.gvtm_generate_tracks_host.argtypes = [i32, ctypes.POINTER(TrackConfig), vp, vp, sz, sz, vp, vp, vp]
     L.gvtm_generate_tracks_host.restype = i32
+    L.gvtm_stream_create.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.gvtm_stream_create.restype = i32
+    L.gvtm_stream_destroy.argtypes = [vp]
+    L.gvtm_stream_destroy.restype = None
+    L.gvtm_stream_reset.argtypes = [vp]
+    L.gvtm_stream_reset.restype = i32
+    L.gvtm_stream_capacity.argtypes = [vp, sz]
+    L.gvtm_stream_capacity.restype = sz
+    L.gvtm_stream_push.argtypes = [vp, vp, vp, sz, vp, sz, vp]
+    L.gvtm_stream_push.restype = i32
+    L.gvtm_stream_finish.argtypes = [vp, vp, sz, vp, vp]
+    L.gvtm_stream_finish.restype = i32
     L.gvtm_plan_set_timing.argtypes = [vp, i32]
     L.gvtm_plan_set_timing.restype = i32
     L.gvtm_plan_take_kernel_ms.argtypes = [vp, ctypes.POINTER(i32)]
@@ -391,3 +403,54 @@ class Plan:
         self._check(self._lib.gvtm_normalize_batch_device(
             self._h, _ptr(d_audio), int(batch), int(audio_stride), _ptr(d_counts), _ptr(d_maxabs), _ptr(d_out_f32),
             _ptr(d_out_i16), _ptr(d_scales), _ptr(stream)))
+
+
+class Stream:
+    """Owns a gvtm_stream: `batch` utterances of a plan synthesized piece by piece (include/gama_vtm.h, "Streams")."""
+
+    def __init__(self, plan, batch):
+        self._plan = plan  # keeps the plan alive
+        self._lib = plan._lib
+        self._h = ctypes.c_void_p()
+        self.batch = int(batch)
+        plan._check(self._lib.gvtm_stream_create(plan._h, self.batch, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.gvtm_stream_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self._plan._check(self._lib.gvtm_stream_reset(self._h))
+
+    def capacity(self, max_new_frames):
+        return int(self._lib.gvtm_stream_capacity(self._h, int(max_new_frames)))
+
+    def push(self, params, frame_counts=None):
+        """params float32 [batch][F][16] -> list of float32 arrays, the new samples of each utterance."""
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        assert params.ndim == 3 and params.shape[0] == self.batch and params.shape[2] == N_PARAM
+        frames = params.shape[1]
+        stride = self.capacity(frames)
+        audio = np.zeros((self.batch, stride), dtype=np.float32)
+        counts = np.zeros(self.batch, dtype=np.int64)
+        fc = None
+        if frame_counts is not None:
+            fc = np.ascontiguousarray(frame_counts, dtype=np.int32)
+        self._plan._check(self._lib.gvtm_stream_push(self._h, _ptr(params), _ptr(fc), frames, _ptr(audio), stride, _ptr(counts)))
+        return [audio[b, : counts[b]].copy() for b in range(self.batch)]
+
+    def finish(self):
+        """-> (list of float32 arrays, maxabs float32 [batch])"""
+        stride = self.capacity(0)
+        audio = np.zeros((self.batch, stride), dtype=np.float32)
+        counts = np.zeros(self.batch, dtype=np.int64)
+        maxabs = np.zeros(self.batch, dtype=np.float32)
+        self._plan._check(self._lib.gvtm_stream_finish(self._h, _ptr(audio), stride, _ptr(counts), _ptr(maxabs)))
+        return [audio[b, : counts[b]].copy() for b in range(self.batch)], maxabs

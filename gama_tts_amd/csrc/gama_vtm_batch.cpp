@@ -11,6 +11,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -49,17 +50,25 @@ int main(int argc, char** argv)
 	try {
 		gvtm::BatchController controller(argv[i], devices, precision);
 		const std::string out_dir = argv[i + 1];
+		// output names first: two inputs with the same basename would write the same WAV
 		std::vector<std::string> names;
+		std::set<std::string> seen;
 		for (int a = i + 2; a < argc; ++a) {
-			std::ifstream in(argv[a], std::ios_base::binary);
-			if (!in) { std::cerr << "Could not open the file " << argv[a] << '.' << std::endl; return EXIT_FAILURE; }
-			controller.addUtteranceFromStream(in);
 			std::string base = argv[a];
 			const auto slash = base.find_last_of('/');
 			if (slash != std::string::npos) base = base.substr(slash + 1);
 			const auto dot = base.find_last_of('.');
 			if (dot != std::string::npos) base = base.substr(0, dot);
+			if (!seen.insert(base).second) {
+				std::cerr << "Two parameter files share the basename '" << base << "': their output would be the same file " << out_dir << '/' << base << ".wav." << std::endl;
+				return EXIT_FAILURE;
+			}
 			names.push_back(base);
+		}
+		for (int a = i + 2; a < argc; ++a) {
+			std::ifstream in(argv[a], std::ios_base::binary);
+			if (!in) { std::cerr << "Could not open the file " << argv[a] << '.' << std::endl; return EXIT_FAILURE; }
+			controller.addUtteranceFromStream(in);
 		}
 		controller.synthesize();
 		for (std::size_t u = 0; u < controller.size(); ++u) {

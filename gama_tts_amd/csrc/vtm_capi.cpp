@@ -517,9 +517,22 @@ double gvtm_plan_take_kernel_ms(gvtm_plan* plan, int* launches_out)
 	return n ? total / n : -1.0;
 }
 
-int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_counts,
+} // extern "C"
+
+namespace {
+
+// what a launch on behalf of a stream adds to the one-shot launch
+struct StreamLaunch {
+	unsigned char* d_state;
+	size_t stride;
+	int mode;     // gvtm::StreamMode
+	int xr;       // the stream's ring length (one for all shapes)
+	int rows;     // 1 unless the utterances are in lockstep
+};
+
+int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_counts,
 		size_t batch, size_t max_frames, float* d_audio, size_t audio_stride,
-		int64_t* d_out_counts, float* d_maxabs, void* hip_stream)
+		int64_t* d_out_counts, float* d_maxabs, void* hip_stream, const StreamLaunch* sl)
 {
 	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
 	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan (GVTM_DEVICE_NONE): there is no CPU synthesis path");
@@ -530,17 +543,19 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	if (static_cast<unsigned long long>(max_frames) * plan->design.k.control_steps + 4096ull >= (1ull << 31)) {
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "max_frames * control_steps does not fit the 31-bit step counter");
 	}
-	if (audio_stride < gvtm_output_count(plan, max_frames)) {
+	if (!sl && audio_stride < gvtm_output_count(plan, max_frames)) {
 		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
 	}
 	const bool model5 = plan->design.model5;
 	const gvtm::DeviceConstants& k = plan->design.k;
 	constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 	int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows, k.section_delay);
+	if (sl && sl->rows == 1) rows = 1;
+	const int xr_fixed = sl ? sl->xr : 0;
 	// a shape whose rings do not fit (down-sampling plans carry the reference's 1024-sample ring per row) gives way to
 	// the next smaller one
-	while (!model5 && rows > 1 && gvtm::synth_lds_bytes(k, plan->precision, rows) > kLdsPerWorkgroup) rows /= 2;
-	if ((model5 ? gvtm::synth5_lds_bytes() : gvtm::synth_lds_bytes(k, plan->precision, rows)) > kLdsPerWorkgroup) {
+	while (!model5 && rows > 1 && gvtm::synth_lds_bytes(k, plan->precision, rows, xr_fixed) > kLdsPerWorkgroup) rows /= 2;
+	if ((model5 ? gvtm::synth5_lds_bytes() : gvtm::synth_lds_bytes(k, plan->precision, rows, xr_fixed)) > kLdsPerWorkgroup) {
 		return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
 	}
 
@@ -564,7 +579,12 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	args.max_frames = max_frames;
 	args.audio_stride = audio_stride;
 	args.batch = batch;
-	args.xr = model5 ? 0 : gvtm::synth_ring_length(k, plan->precision, rows);
+	args.xr = model5 ? 0 : (sl ? sl->xr : gvtm::synth_ring_length(k, plan->precision, rows));
+	if (sl) {
+		args.stream = sl->d_state;
+		args.stream_stride = sl->stride;
+		args.stream_mode = sl->mode;
+	}
 	args.debug_taps = plan->debug_taps;
 	args.phase_cycles = plan->phase_cycles;
 	args.k5const = plan->d_consts5;
@@ -588,6 +608,17 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	}
 	if (e != hipSuccess) return fail_hip(e, "vtm_synth_kernel launch");
 	return GVTM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_counts,
+		size_t batch, size_t max_frames, float* d_audio, size_t audio_stride,
+		int64_t* d_out_counts, float* d_maxabs, void* hip_stream)
+{
+	return launch_batch(plan, d_params, d_frame_counts, batch, max_frames, d_audio, audio_stride, d_out_counts, d_maxabs, hip_stream, nullptr);
 }
 
 int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
@@ -697,6 +728,239 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 	}
 	if (!bad.empty()) g_last_error = "frame_counts entry outside [0, max_frames]: those utterances have out_counts = -1";
 	return GVTM_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Streams: the stateful form of the path (include/gama_vtm.h, "Streams").
+ */
+
+} // extern "C"
+
+struct gvtm_stream {
+	gvtm_plan* plan = nullptr;
+	size_t batch = 0;
+	size_t state_stride = 0;
+	int xr = 0;
+	unsigned granule_frames = 1;          // pushes are synthesized in multiples of this many frames (12 internal steps)
+	DeviceBuffer d_state, d_params, d_frames, d_audio, d_counts, d_maxabs;
+	std::vector<std::vector<float>> held; // per utterance: frames pushed but not yet synthesized (the last one is the look-ahead)
+	std::vector<uint64_t> steps_done;     // per utterance: internal steps synthesized
+	std::vector<float> staging;
+	std::vector<int32_t> counts;
+	bool finished = false;
+};
+
+namespace {
+
+unsigned gcd_u(unsigned a, unsigned b)
+{
+	while (b) { const unsigned t = a % b; a = b; b = t; }
+	return a;
+}
+
+int stream_upload_fresh_state(gvtm_stream* s)
+{
+	std::vector<unsigned char> init(s->state_stride * s->batch, 0);
+	for (size_t b = 0; b < s->batch; ++b) {
+		gvtm::StreamHeader h{};
+		h.seed = 0.7892347; // NoiseSource::reset (vtm/NoiseSource.h:32-34)
+		std::memcpy(init.data() + b * s->state_stride, &h, sizeof(h));
+	}
+	hipError_t e = hipMemcpy(s->d_state.ptr, init.data(), init.size(), hipMemcpyHostToDevice);
+	if (e != hipSuccess) return fail_hip(e, "H2D stream state");
+	return GVTM_OK;
+}
+
+uint64_t outputs_before(const gvtm::DeviceConstants& k, uint64_t steps)
+{
+	return ((steps << 16) + k.time_inc - 1) / k.time_inc;
+}
+
+// One launch on behalf of the stream: utterance b synthesizes n_frames[b] frames from the front of held[b].
+int stream_launch(gvtm_stream* s, const std::vector<size_t>& n_frames, bool final, float* audio, size_t audio_stride, int64_t* out_counts,
+		float* maxabs)
+{
+	gvtm_plan* plan = s->plan;
+	const gvtm::DeviceConstants& k = plan->design.k;
+	const size_t batch = s->batch;
+	size_t rows_max = 0;
+	bool lockstep = true, any = final;
+	for (size_t b = 0; b < batch; ++b) {
+		const size_t rows = n_frames[b] + (final ? 0 : 1); // a push carries the look-ahead frame behind its last one
+		rows_max = std::max(rows_max, n_frames[b] ? rows : size_t(0));
+		if (n_frames[b] != n_frames[0] || s->steps_done[b] != s->steps_done[0]) lockstep = false;
+		if (n_frames[b]) any = true;
+	}
+	// exact sample counts, known before the launch
+	size_t need = 0;
+	std::vector<int64_t> want(batch, 0);
+	for (size_t b = 0; b < batch; ++b) {
+		const uint64_t after = s->steps_done[b] + static_cast<uint64_t>(n_frames[b]) * k.control_steps;
+		if (after + 4096ull >= (1ull << 31)) return fail(GVTM_ERR_INVALID_ARGUMENT, "a stream holds at most 2^31 internal steps between resets");
+		const uint64_t k0 = outputs_before(k, s->steps_done[b]);
+		const uint64_t k1 = final ? gvtm::src_output_count(k.time_inc, k.pad, k.upsampling, after) : outputs_before(k, after);
+		want[b] = static_cast<int64_t>(k1 - k0);
+		need = std::max(need, static_cast<size_t>(want[b]));
+	}
+	if (need > audio_stride) return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than this call produces (gvtm_stream_capacity)");
+	if (need > 0 && !audio) return fail(GVTM_ERR_INVALID_ARGUMENT, "null audio buffer");
+	if (!any) {
+		if (out_counts) std::fill(out_counts, out_counts + batch, int64_t(0));
+		return GVTM_OK;
+	}
+	if (rows_max == 0) rows_max = 1;
+	DeviceScope scope(plan->device);
+	hipError_t e = scope.status();
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	try {
+		s->staging.assign(batch * rows_max * GVTM_N_PARAM, 0.0f);
+		s->counts.assign(batch, 0);
+	} catch (const std::bad_alloc&) {
+		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
+	}
+	for (size_t b = 0; b < batch; ++b) {
+		if (!n_frames[b]) continue;
+		const size_t rows = n_frames[b] + (final ? 0 : 1);
+		std::memcpy(s->staging.data() + b * rows_max * GVTM_N_PARAM, s->held[b].data(), sizeof(float) * rows * GVTM_N_PARAM);
+		s->counts[b] = static_cast<int32_t>(n_frames[b]);
+	}
+	const size_t pbytes = sizeof(float) * s->staging.size();
+	const size_t abytes = sizeof(float) * batch * std::max<size_t>(audio_stride, 1);
+	if ((e = s->d_params.ensure(pbytes)) != hipSuccess) return fail_hip(e, "hipMalloc params");
+	if ((e = s->d_frames.ensure(sizeof(int32_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc frames");
+	if ((e = s->d_audio.ensure(abytes)) != hipSuccess) return fail_hip(e, "hipMalloc audio");
+	if ((e = s->d_counts.ensure(sizeof(int64_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc counts");
+	if ((e = s->d_maxabs.ensure(sizeof(float) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc maxabs");
+	if ((e = hipMemcpy(s->d_params.ptr, s->staging.data(), pbytes, hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "H2D params");
+	if ((e = hipMemcpy(s->d_frames.ptr, s->counts.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "H2D frame counts");
+	if ((e = hipMemsetAsync(s->d_audio.ptr, 0, abytes, nullptr)) != hipSuccess) return fail_hip(e, "hipMemsetAsync");
+	StreamLaunch sl{static_cast<unsigned char*>(s->d_state.ptr), s->state_stride, final ? gvtm::kStreamFinish : gvtm::kStreamPush, s->xr, lockstep ? 0 : 1};
+	const int rc = launch_batch(plan, static_cast<const float*>(s->d_params.ptr), static_cast<const int32_t*>(s->d_frames.ptr), batch, rows_max,
+			static_cast<float*>(s->d_audio.ptr), audio_stride, static_cast<int64_t*>(s->d_counts.ptr), static_cast<float*>(s->d_maxabs.ptr), nullptr, &sl);
+	if (rc != GVTM_OK) return rc;
+	if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
+	std::vector<int64_t> got(batch, 0);
+	if ((e = hipMemcpy(got.data(), s->d_counts.ptr, sizeof(int64_t) * batch, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H counts");
+	for (size_t b = 0; b < batch; ++b) {
+		if (got[b] != want[b]) return fail(GVTM_ERR_HIP, "internal error: the device's sample count differs from the host's");
+	}
+	if (audio && audio_stride && (e = hipMemcpy(audio, s->d_audio.ptr, sizeof(float) * batch * audio_stride, hipMemcpyDeviceToHost)) != hipSuccess) {
+		return fail_hip(e, "D2H audio");
+	}
+	if (out_counts) std::copy(got.begin(), got.end(), out_counts);
+	if (maxabs && (e = hipMemcpy(maxabs, s->d_maxabs.ptr, sizeof(float) * batch, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H maxabs");
+	for (size_t b = 0; b < batch; ++b) {
+		s->steps_done[b] += static_cast<uint64_t>(n_frames[b]) * k.control_steps;
+		s->held[b].erase(s->held[b].begin(), s->held[b].begin() + static_cast<std::ptrdiff_t>(n_frames[b] * GVTM_N_PARAM));
+	}
+	return GVTM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int gvtm_stream_create(gvtm_plan* plan, size_t batch, gvtm_stream** stream_out)
+{
+	if (!plan || !stream_out || batch == 0) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan / stream_out or empty batch");
+	*stream_out = nullptr;
+	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan (GVTM_DEVICE_NONE): there is no CPU synthesis path");
+	if (plan->design.model5) return fail(GVTM_ERR_UNSUPPORTED, "streams are not implemented for reference model 5 plans");
+	try {
+		std::unique_ptr<gvtm_stream> s(new gvtm_stream);
+		s->plan = plan;
+		s->batch = batch;
+		const gvtm::DeviceConstants& k = plan->design.k;
+		s->xr = gvtm::synth_ring_length(k, plan->precision, 1);
+		s->state_stride = gvtm::stream_state_bytes(k, plan->precision, s->xr);
+		// the serial wavefronts work in blocks of 2, 4 and 4 or 6 steps (vtm_kernel_v2.inc): their states are exact at
+		// multiples of 12 steps, so a push synthesizes a multiple of 12 / gcd(control_steps, 12) frames and keeps the rest
+		s->granule_frames = 12u / gcd_u(k.control_steps, 12u);
+		s->held.resize(batch);
+		s->steps_done.assign(batch, 0);
+		DeviceScope scope(plan->device);
+		hipError_t e = scope.status();
+		if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+		if ((e = s->d_state.ensure(s->state_stride * batch)) != hipSuccess) return fail_hip(e, "hipMalloc stream state");
+		const int rc = stream_upload_fresh_state(s.get());
+		if (rc != GVTM_OK) { s->d_state.release(); return rc; }
+		*stream_out = s.release();
+		return GVTM_OK;
+	} catch (const std::bad_alloc&) {
+		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
+	}
+}
+
+void gvtm_stream_destroy(gvtm_stream* s)
+{
+	if (!s) return;
+	{
+		DeviceScope scope(s->plan->device);
+		s->d_state.release(); s->d_params.release(); s->d_frames.release(); s->d_audio.release(); s->d_counts.release(); s->d_maxabs.release();
+	}
+	delete s;
+}
+
+int gvtm_stream_reset(gvtm_stream* s)
+{
+	if (!s) return fail(GVTM_ERR_INVALID_ARGUMENT, "null stream");
+	DeviceScope scope(s->plan->device);
+	if (scope.status() != hipSuccess) return fail_hip(scope.status(), "hipSetDevice");
+	for (auto& h : s->held) h.clear();
+	std::fill(s->steps_done.begin(), s->steps_done.end(), uint64_t(0));
+	s->finished = false;
+	return stream_upload_fresh_state(s);
+}
+
+size_t gvtm_stream_capacity(const gvtm_stream* s, size_t max_new_frames)
+{
+	if (!s) return static_cast<size_t>(-1);
+	const gvtm::DeviceConstants& k = s->plan->design.k;
+	// at most the new frames plus what a push can have kept (granule_frames frames), flushed, with the overrun's lap
+	const uint64_t steps = static_cast<uint64_t>(max_new_frames + s->granule_frames) * k.control_steps;
+	return static_cast<size_t>(gvtm::src_output_capacity(k.time_inc, k.pad, k.upsampling, steps) + 1);
+}
+
+int gvtm_stream_push(gvtm_stream* s, const float* params, const int32_t* frame_counts, size_t max_frames,
+		float* audio, size_t audio_stride, int64_t* out_counts)
+{
+	if (!s) return fail(GVTM_ERR_INVALID_ARGUMENT, "null stream");
+	if (s->finished) return fail(GVTM_ERR_INVALID_ARGUMENT, "the stream has been finished: gvtm_stream_reset() starts the next utterances");
+	if (max_frames > 0 && !params) return fail(GVTM_ERR_INVALID_ARGUMENT, "null params with max_frames > 0");
+	if (frame_counts) {
+		for (size_t b = 0; b < s->batch; ++b) {
+			if (frame_counts[b] < 0 || static_cast<size_t>(frame_counts[b]) > max_frames) return fail(GVTM_ERR_INVALID_ARGUMENT, "frame_counts entry outside [0, max_frames]");
+		}
+	}
+	try {
+		std::vector<size_t> n(s->batch, 0);
+		for (size_t b = 0; b < s->batch; ++b) {
+			const size_t add = frame_counts ? static_cast<size_t>(frame_counts[b]) : max_frames;
+			const float* src = params + b * max_frames * GVTM_N_PARAM;
+			s->held[b].insert(s->held[b].end(), src, src + add * GVTM_N_PARAM);
+			const size_t have = s->held[b].size() / GVTM_N_PARAM;
+			// the last frame held is the look-ahead of the one before it (Controller.cpp:297-300 interpolates towards the NEXT frame)
+			n[b] = have > 0 ? ((have - 1) / s->granule_frames) * s->granule_frames : 0;
+		}
+		return stream_launch(s, n, false, audio, audio_stride, out_counts, nullptr);
+	} catch (const std::bad_alloc&) {
+		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
+	}
+}
+
+int gvtm_stream_finish(gvtm_stream* s, float* audio, size_t audio_stride, int64_t* out_counts, float* maxabs)
+{
+	if (!s) return fail(GVTM_ERR_INVALID_ARGUMENT, "null stream");
+	if (s->finished) return fail(GVTM_ERR_INVALID_ARGUMENT, "the stream has already been finished");
+	try {
+		std::vector<size_t> n(s->batch, 0);
+		for (size_t b = 0; b < s->batch; ++b) n[b] = s->held[b].size() / GVTM_N_PARAM; // the last frame stands for its own successor (Controller.cpp:283)
+		const int rc = stream_launch(s, n, true, audio, audio_stride, out_counts, maxabs);
+		if (rc == GVTM_OK) s->finished = true;
+		return rc;
+	} catch (const std::bad_alloc&) {
+		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
+	}
 }
 
 int gvtm_normalize_batch_device(gvtm_plan* plan, const float* d_audio, size_t batch, size_t audio_stride,

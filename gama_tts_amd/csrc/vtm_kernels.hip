@@ -115,7 +115,9 @@ static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t str
 	constexpr int NH = LAYOUT == 1 ? wide_helpers<U>() : S::NH;
 	constexpr int kWaves = v2::serial_waves<U, LAYOUT>() + NH;
 	auto fn = v2::vtm_synth_kernel<CT, ST, D, S::U, S::C, NH, LAYOUT>;
-	if (args.xr != ring_length(args.k, S::C) || 2 * S::C + 4 * args.k.pad > args.xr) return hipErrorInvalidValue;
+	// (a stream keeps ONE ring length for all shapes, the one-row shape's: longer than this shape needs, never shorter)
+	if (args.xr < ring_length(args.k, S::C) || (args.xr & (args.xr - 1)) != 0 || 2 * S::C + 4 * args.k.pad > args.xr) return hipErrorInvalidValue;
+	if (!args.k.upsampling && args.xr != kSrcRing) return hipErrorInvalidValue;
 	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C>(args.xr);
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
@@ -181,10 +183,18 @@ int synth_ring_length(const DeviceConstants& k, int precision, int rows)
 	return ring_length(k, shape_numbers(precision, rows).chunk);
 }
 
-size_t synth_lds_bytes(const DeviceConstants& k, int precision, int rows)
+size_t stream_state_bytes(const DeviceConstants& k, int precision, int xr)
+{
+	const int lanes = k.layout == 1 ? 48 : 16, words = 2 * k.section_delay + 1;
+	if (precision == GVTM_PRECISION_F32) return StreamLayout<float, float>::bytes(lanes, words, xr);
+	if (precision == GVTM_PRECISION_MIXED) return StreamLayout<double, float>::bytes(lanes, words, xr);
+	return StreamLayout<double, double>::bytes(lanes, words, xr);
+}
+
+size_t synth_lds_bytes(const DeviceConstants& k, int precision, int rows, int xr)
 {
 	const ShapeNumbers n = shape_numbers(precision, rows);
-	return n.lds_fixed + ((n.ring_elem * static_cast<size_t>(ring_length(k, n.chunk)) + 15) & ~size_t(15));
+	return n.lds_fixed + ((n.ring_elem * static_cast<size_t>(xr > 0 ? xr : ring_length(k, n.chunk)) + 15) & ~size_t(15));
 }
 
 template <typename CT, typename ST, int U>

@@ -10,6 +10,38 @@
 
 namespace gvtm {
 
+// ---- streams (gvtm_stream_*): what an utterance carries from one launch to the next, in device memory ----
+//
+//   StreamHeader | scalars CT[kStreamScalars] | tube CT[lanes][2 * SectionDelay + 1] | decimator pre-roll CT[48] | ring ST[xr]
+//
+// i.e. exactly the reference model's members that survive a step (vtm/VocalTractModel0.h:221-252): the section delay
+// lines, the filter memories, the oscillator phase, the noise seed, the decimator's and the converter's buffers with
+// the converter's position (time register and pointers follow from the number of steps, SampleRateConverter.h:268-282).
+// A fresh utterance (create / reset) is all zeros except the noise seed (NoiseSource.h:32-34).
+struct StreamHeader {
+	unsigned long long step_base; // internal steps synthesized so far
+	double seed;                  // NoiseSource::seed_
+	unsigned peak_bits;           // running max |sample| as float bits
+	unsigned reserved_;
+	unsigned long long pad_;
+};
+static_assert(sizeof(StreamHeader) == 32, "stream header layout");
+constexpr int kStreamScalars = 12;
+constexpr int kSsPos = 0, kSsPrev = 1;           // oscillator position, previous white-noise sample
+constexpr int kSsBp = 2, kSsThr = 6;             // band-pass x1 x2 y1 y2, throat y1
+constexpr int kSsRadMouth = 7, kSsRadNose = 9;   // radiation filters {x1, y1}
+constexpr int kStreamPreRoll = 48;               // = kWPre of the kernel
+enum StreamMode : int { kStreamNone = 0, kStreamPush = 1, kStreamFinish = 2 };
+
+template <typename CT, typename ST>
+struct StreamLayout {
+	static constexpr size_t scalars() { return sizeof(StreamHeader); }
+	static constexpr size_t tube() { return scalars() + sizeof(CT) * kStreamScalars; }
+	static constexpr size_t wpre(int lanes, int words) { return tube() + sizeof(CT) * static_cast<size_t>(lanes) * words; }
+	static constexpr size_t ring(int lanes, int words) { return wpre(lanes, words) + sizeof(CT) * kStreamPreRoll; }
+	static constexpr size_t bytes(int lanes, int words, int xr) { return (ring(lanes, words) + sizeof(ST) * static_cast<size_t>(xr) + 15) & ~size_t(15); }
+};
+
 struct SynthArgs {
 	DeviceConstants k;              // by value (host-side launch decisions)
 	const DeviceConstants* kconst;  // the same constants in device memory (the kernel stages them in LDS)
@@ -26,6 +58,9 @@ struct SynthArgs {
 	size_t audio_stride;
 	size_t batch;
 	int xr;                      // internal-rate ring length per utterance (a power of two; synth_ring_length())
+	unsigned char* stream = nullptr; // null, or [batch] stream states of stream_stride bytes each (layout above)
+	size_t stream_stride = 0;
+	int stream_mode = kStreamNone;   // StreamMode
 	double* debug_taps;          // null, or [batch][max_frames*control_steps][8] per-step taps (tests only)
 	unsigned long long* phase_cycles; // null, or [workgroups][16] shader cycles per role wavefront and helper stage (diagnostics only)
 	const Model5Constants* k5const = nullptr; // model 5 only: its constants in device memory
@@ -48,8 +83,11 @@ int synth_rows(int precision, size_t batch, int requested, int section_delay = 1
 // overrun aliases as the reference's ring does; otherwise the smallest power of two holding two chunks, the
 // resampler's history and the flush zeros
 int synth_ring_length(const DeviceConstants& k, int precision, int rows);
-size_t synth_lds_bytes(const DeviceConstants& k, int precision, int rows);
+size_t synth_lds_bytes(const DeviceConstants& k, int precision, int rows, int xr = 0 /* 0: the shape's own ring length */);
 hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int rows, hipStream_t stream);
+// bytes of one utterance's stream state for a plan (ring length of the one-row shape: streams whose utterances are not in
+// lockstep run one utterance per workgroup, and every shape of a stream uses that ring length)
+size_t stream_state_bytes(const DeviceConstants& k, int precision, int xr);
 // reference model 5 (VocalTractModel5<double,1>): one utterance per workgroup, fp64
 size_t synth5_lds_bytes();
 hipError_t launch_synth5(const SynthArgs& args, size_t batch, hipStream_t stream);

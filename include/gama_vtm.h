@@ -24,6 +24,10 @@
  *                               execSynthesisStep / finishSynthesis for B utterances
  *                               (vtm_control_model/Controller.cpp:277-313,
  *                               vtm/VocalTractModel0.h:396-445, :698-723)
+ *   gvtm_stream_*               the same three calls as a STATEFUL object: what VocalTractModel keeps between
+ *                               execSynthesisStep() calls (vtm/VocalTractModel0.h:221-252, :396-445), reset() (:309-326)
+ *                               and finishSynthesis() (:720-723), so that an utterance can be handed over in pieces
+ *                               (long tracks; the editor's interactive polling, InteractiveAudio.cpp:141-185)
  *   gvtm_normalize_batch_device Controller::writeOutputToBuffer / writeOutputToFile scaling,
  *                               Util::calculateOutputScale (Controller.cpp:315-340,
  *                               vtm/VTMUtil.cpp:48-67, WAVEFileWriter.cpp:122-125)
@@ -225,6 +229,41 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
 		size_t batch, size_t max_frames, float* audio, size_t audio_stride,
 		int64_t* out_counts, float* maxabs);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streams: a batch of utterances synthesized piece by piece.
+ *
+ * The reference model is an object with state: every execSynthesisStep() continues where the last one stopped, and
+ * the caller may read outputBuffer() whenever it likes (the editor does, after every step).  A gvtm_stream keeps that
+ * state for `batch` independent utterances in device memory between launches: section delay lines, filter memories,
+ * oscillator phase, noise seed, the decimator's and the converter's buffers and the converter's position.  Pushing an
+ * utterance in any number of pieces and finishing it yields exactly the samples of the one-shot entry points
+ * (bit for bit, in every precision).
+ *
+ *   gvtm_stream_push    appends frames; synthesizes every frame whose successor is known (the driver loop interpolates
+ *                       each frame TOWARDS the next one, Controller.cpp:297-300), in multiples of a few frames (the
+ *                       wavefronts' recurrences are unrolled: 12 internal steps), keeps the rest; returns the new samples
+ *   gvtm_stream_finish  synthesizes what is kept (the last frame stands for its own successor, Controller.cpp:283) and
+ *                       flushes the converter (finishSynthesis()); maxabs = max |sample| of the whole utterance
+ *   gvtm_stream_reset   every utterance back to the state after construction (VocalTractModel::reset())
+ *
+ * Utterances pushed in lockstep (same frame counts every time) share workgroups like a one-shot batch; otherwise a
+ * workgroup takes one utterance.  Not implemented for reference model 5 plans (GVTM_ERR_UNSUPPORTED).
+ */
+typedef struct gvtm_stream gvtm_stream;
+
+int gvtm_stream_create(gvtm_plan* plan, size_t batch, gvtm_stream** stream_out);
+void gvtm_stream_destroy(gvtm_stream* stream);
+int gvtm_stream_reset(gvtm_stream* stream);
+/* Samples per utterance that a push of at most max_new_frames frames, or the finish after it, can return: the
+ * audio_stride to allocate. */
+size_t gvtm_stream_capacity(const gvtm_stream* stream, size_t max_new_frames);
+/* params [batch][max_frames][16] float32 (host), frame_counts [batch] new frames per utterance or NULL (max_frames each);
+ * audio [batch][audio_stride] float32 (host) receives the new samples of each utterance from index 0, out_counts[b]
+ * how many (may be NULL); rows are zero beyond their count.  Synchronous. */
+int gvtm_stream_push(gvtm_stream* stream, const float* params, const int32_t* frame_counts, size_t max_frames,
+		float* audio, size_t audio_stride, int64_t* out_counts);
+int gvtm_stream_finish(gvtm_stream* stream, float* audio, size_t audio_stride, int64_t* out_counts, float* maxabs);
 
 /* Output scaling of Controller::writeOutputToBuffer / writeOutputToFile: scale = 0.95 / max|x|
  * (0 when max < 1e-30).  Exactly one of d_out_f32 / d_out_i16 may be non-NULL; i16 applies the
