@@ -1,6 +1,10 @@
 // libgama_vtm_plugin.so — GamaTTS VocalTractModel plugin over the C ABI of libgama_vtm.so.
 // See include/gama_vtm_plugin.h for the contract.  Host-side C++ only; all synthesis happens
-// in gvtm_synthesize_batch_host().
+// in gvtm_synthesize_batch_host() (batch-friendly protocol: the steps are recorded and synthesized at
+// finishSynthesis()) or in a gvtm_stream (interactive protocol: outputBuffer() is polled after every
+// execSynthesisStep(), gama_tts_editor/src/interactive/InteractiveAudio.cpp:141-185, so the steps go to the
+// device in blocks and the samples appear in bursts, as the reference's own converter delivers them every
+// 998 steps, vtm/SampleRateConverter.h:277-281).
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -63,9 +67,13 @@ private:
 
 class DeviceVocalTractModel final : public VocalTractModelAbi {
 public:
-	explicit DeviceVocalTractModel(const ConfigurationDataMirror& data)
+	DeviceVocalTractModel(const ConfigurationDataMirror& data, bool interactive)
+		: interactive_(interactive)
 	{
 		const KeyReader k(data);
+		if (interactive && k.has("gpu_model") && k.integer("gpu_model") == 5) {
+			throw std::runtime_error("interactive use of reference model 5 is not served by the device backend (gvtm_stream_create: unsupported)");
+		}
 		const int device = k.has("gpu_device") ? k.integer("gpu_device") : 0;
 		if (k.has("gpu_model") && k.integer("gpu_model") == 5) {
 			// the keys of VocalTractModel5::loadConfiguration (vtm/VocalTractModel5.h:375-421)
@@ -161,13 +169,34 @@ public:
 		if (info.control_steps != 1) throw std::runtime_error("internal error: plugin plan must run one step per frame");
 		current_.assign(GVTM_N_PARAM, 0.0f);
 		output_.reserve(1024);
+		if (interactive_) {
+			// steps per launch: the reference's converter hands its samples over every 998 fills; a multiple of 12 near it
+			int block = k.has("gpu_interactive_block") ? k.integer("gpu_interactive_block") : 996;
+			block_steps_ = static_cast<std::size_t>(block < 12 ? 12 : ((block + 11) / 12) * 12);
+			if (gvtm_stream_create(plan_, 1, &stream_) != GVTM_OK) {
+				const std::string why = gvtm_last_error();
+				gvtm_plan_destroy(plan_);
+				plan_ = nullptr;
+				throw std::runtime_error(why);
+			}
+			burst_.resize(gvtm_stream_capacity(stream_, block_steps_));
+		}
 	}
-	~DeviceVocalTractModel() noexcept override { gvtm_plan_destroy(plan_); }
+	~DeviceVocalTractModel() noexcept override
+	{
+		gvtm_stream_destroy(stream_);
+		gvtm_plan_destroy(plan_);
+	}
 
 	void reset() noexcept override
 	{
 		steps_.clear();
 		output_.clear();
+		failed_ = false;
+		if (stream_ && gvtm_stream_reset(stream_) != GVTM_OK) {
+			std::fprintf(stderr, "[gama_vtm_plugin] reset failed: %s\n", gvtm_last_error());
+			failed_ = true;
+		}
 	}
 	double internalSampleRate() const noexcept override { return internal_rate_; }
 	double outputSampleRate() const noexcept override { return output_rate_; }
@@ -185,36 +214,86 @@ public:
 	{
 		try {
 			steps_.insert(steps_.end(), current_.begin(), current_.end());
+			if (interactive_ && steps_.size() >= block_steps_ * GVTM_N_PARAM) pushBlock();
 		} catch (...) {
 			failed_ = true;
 		}
 	}
 	void finishSynthesis() noexcept override
 	{
+		// Whatever happens, the next utterance starts from a clean recording: the reference's Controller only calls
+		// reset() when outputBuffer() is not empty (Controller.cpp:231), and a failed utterance leaves it empty.
 		try {
-			const std::size_t n_steps = steps_.size() / GVTM_N_PARAM;
-			const std::size_t n_out = gvtm_output_count(plan_, n_steps);
-			if (failed_ || n_out == static_cast<std::size_t>(-1)) {
-				std::fprintf(stderr, "[gama_vtm_plugin] cannot synthesize: %s\n", failed_ ? "out of memory while recording" : gvtm_last_error());
-				output_.clear();
-				return;
+			if (interactive_) {
+				finishStream();
+			} else {
+				finishRecorded();
 			}
-			output_.assign(n_out, 0.0f);
-			int64_t written = 0;
-			const int rc = gvtm_synthesize_batch_host(plan_, steps_.data(), nullptr, 1, n_steps, output_.data(), n_out, &written, nullptr);
-			if (rc != GVTM_OK) {
-				std::fprintf(stderr, "[gama_vtm_plugin] synthesis failed: %s\n", gvtm_last_error());
-				output_.clear();
-				return;
-			}
-			output_.resize(static_cast<std::size_t>(written));
-			steps_.clear();
 		} catch (...) {
 			output_.clear();
 		}
+		steps_.clear();
+		failed_ = false;
 	}
 	std::vector<float>& outputBuffer() noexcept override { return output_; }
 private:
+	void finishRecorded()
+	{
+		const std::size_t n_steps = steps_.size() / GVTM_N_PARAM;
+		const std::size_t n_out = gvtm_output_count(plan_, n_steps);
+		if (failed_ || n_out == static_cast<std::size_t>(-1)) {
+			std::fprintf(stderr, "[gama_vtm_plugin] cannot synthesize: %s\n", failed_ ? "out of memory while recording" : gvtm_last_error());
+			output_.clear();
+			return;
+		}
+		output_.assign(n_out, 0.0f);
+		int64_t written = 0;
+		const int rc = gvtm_synthesize_batch_host(plan_, steps_.data(), nullptr, 1, n_steps, output_.data(), n_out, &written, nullptr);
+		if (rc != GVTM_OK || written < 0) {
+			std::fprintf(stderr, "[gama_vtm_plugin] synthesis failed: %s\n", gvtm_last_error());
+			output_.clear();
+			return;
+		}
+		output_.resize(static_cast<std::size_t>(written));
+	}
+	// interactive protocol: the recorded steps go to the stream, the samples it returns are appended to the buffer the
+	// host is polling (the host may have emptied it in between: Util::getSamples, vtm/VTMUtil.cpp:41-44)
+	void pushBlock()
+	{
+		if (failed_) { steps_.clear(); return; }
+		const std::size_t n_steps = steps_.size() / GVTM_N_PARAM;
+		const std::size_t cap = gvtm_stream_capacity(stream_, n_steps);
+		if (burst_.size() < cap) burst_.resize(cap);
+		int64_t n = 0;
+		if (gvtm_stream_push(stream_, steps_.data(), nullptr, n_steps, burst_.data(), burst_.size(), &n) != GVTM_OK) {
+			std::fprintf(stderr, "[gama_vtm_plugin] synthesis failed: %s\n", gvtm_last_error());
+			failed_ = true;
+		} else {
+			output_.insert(output_.end(), burst_.begin(), burst_.begin() + n);
+		}
+		steps_.clear();
+	}
+	void finishStream()
+	{
+		if (!steps_.empty()) pushBlock();
+		if (failed_) { output_.clear(); return; }
+		const std::size_t cap = gvtm_stream_capacity(stream_, 0);
+		if (burst_.size() < cap) burst_.resize(cap);
+		int64_t n = 0;
+		if (gvtm_stream_finish(stream_, burst_.data(), burst_.size(), &n, nullptr) != GVTM_OK) {
+			std::fprintf(stderr, "[gama_vtm_plugin] synthesis failed: %s\n", gvtm_last_error());
+			output_.clear();
+			return;
+		}
+		output_.insert(output_.end(), burst_.begin(), burst_.begin() + n);
+		// the stream is finished: the next utterance needs a fresh one whether or not the host calls reset()
+		if (gvtm_stream_reset(stream_) != GVTM_OK) failed_ = true;
+	}
+
+	const bool interactive_;
+	gvtm_stream* stream_ = nullptr;
+	std::size_t block_steps_ = 996;
+	std::vector<float> burst_;
 	gvtm_plan* plan_ = nullptr;
 	double internal_rate_ = 0.0;
 	double output_rate_ = 0.0;
@@ -231,12 +310,8 @@ extern "C" {
 void* GAMA_TTS_construct_vocal_tract_model(const void* config_data, int is_interactive)
 {
 	if (!config_data) return nullptr;
-	if (is_interactive) {
-		std::fprintf(stderr, "[gama_vtm_plugin] interactive (per-step polled) use is not served by the device backend\n");
-		return nullptr;
-	}
 	try {
-		return static_cast<VocalTractModelAbi*>(new DeviceVocalTractModel(*static_cast<const ConfigurationDataMirror*>(config_data)));
+		return static_cast<VocalTractModelAbi*>(new DeviceVocalTractModel(*static_cast<const ConfigurationDataMirror*>(config_data), is_interactive != 0));
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "[gama_vtm_plugin] construct failed: %s\n", e.what());
 	} catch (...) {

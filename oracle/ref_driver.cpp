@@ -23,6 +23,13 @@
 //            "2000:<path>" = plugin factory with dll_path=<path>
 //   [repeat] > 1: timing mode, the utterance is synthesised <repeat> times
 //            (reset() between runs, as Controller does, Controller.cpp:231).
+//   [poll=<nframes>]: the INTERACTIVE caller contract instead (the model is constructed with interactive = true and
+//            driven the way gama_tts_editor/src/interactive/InteractiveAudio.cpp:141-185 drives it from its JACK
+//            callback): per callback, drain outputBuffer() with Util::getSamples (which clears it when used up), then
+//            `while (outputBuffer().size() < needed) { setParameter x 16; execSynthesisStep(); }`; the per-step
+//            parameter values are the driver loop's, every callback asks for <nframes> samples; when the steps
+//            are used up finishSynthesis() is called and the rest drained.  <out.f32> receives the drained samples
+//            (scale 1), which must be the same stream as in the batch protocol.
 // prints one line:  N=<samples> steps=<internal steps> fs=<internal rate>
 //                   sec=<wall of all repeats> ns_per_step=<...>
 #include <chrono>
@@ -35,6 +42,7 @@
 #include <vector>
 
 #include "ConfigurationData.h"
+#include "VTMUtil.h"
 #include "VocalTractModel.h"
 #include "VocalTractModel2.h"
 #include "VocalTractModel4.h"
@@ -43,17 +51,17 @@
 using GS::ConfigurationData;
 using GS::VTM::VocalTractModel;
 
-static std::unique_ptr<VocalTractModel> make_model(ConfigurationData& cfg, const std::string& model)
+static std::unique_ptr<VocalTractModel> make_model(ConfigurationData& cfg, const std::string& model, bool interactive = false)
 {
 	if (model.rfind("2:", 0) == 0) {
 		const int d = std::atoi(model.c_str() + 2);
 		cfg.put("model", "2");
 		cfg.put("log_parameters", "false");
 		switch (d) {
-		case 1: return std::make_unique<GS::VTM::VocalTractModel2<double, 1>>(cfg, false);
-		case 2: return std::make_unique<GS::VTM::VocalTractModel2<double, 2>>(cfg, false);
-		case 3: return std::make_unique<GS::VTM::VocalTractModel2<double, 3>>(cfg, false);
-		case 4: return std::make_unique<GS::VTM::VocalTractModel2<double, 4>>(cfg, false);
+		case 1: return std::make_unique<GS::VTM::VocalTractModel2<double, 1>>(cfg, interactive);
+		case 2: return std::make_unique<GS::VTM::VocalTractModel2<double, 2>>(cfg, interactive);
+		case 3: return std::make_unique<GS::VTM::VocalTractModel2<double, 3>>(cfg, interactive);
+		case 4: return std::make_unique<GS::VTM::VocalTractModel2<double, 4>>(cfg, interactive);
 		default:
 			std::fprintf(stderr, "unsupported SectionDelay %d\n", d);
 			std::exit(2);
@@ -64,10 +72,10 @@ static std::unique_ptr<VocalTractModel> make_model(ConfigurationData& cfg, const
 		cfg.put("model", "2");
 		cfg.put("log_parameters", "false");
 		switch (d) {
-		case 1: return std::make_unique<GS::VTM::VocalTractModel2<float, 1>>(cfg, false);
-		case 2: return std::make_unique<GS::VTM::VocalTractModel2<float, 2>>(cfg, false);
-		case 3: return std::make_unique<GS::VTM::VocalTractModel2<float, 3>>(cfg, false);
-		case 4: return std::make_unique<GS::VTM::VocalTractModel2<float, 4>>(cfg, false);
+		case 1: return std::make_unique<GS::VTM::VocalTractModel2<float, 1>>(cfg, interactive);
+		case 2: return std::make_unique<GS::VTM::VocalTractModel2<float, 2>>(cfg, interactive);
+		case 3: return std::make_unique<GS::VTM::VocalTractModel2<float, 3>>(cfg, interactive);
+		case 4: return std::make_unique<GS::VTM::VocalTractModel2<float, 4>>(cfg, interactive);
 		default:
 			std::fprintf(stderr, "unsupported SectionDelay %d\n", d);
 			std::exit(2);
@@ -76,21 +84,21 @@ static std::unique_ptr<VocalTractModel> make_model(ConfigurationData& cfg, const
 	if (model == "4f") {
 		cfg.put("model", "4");
 		cfg.put("log_parameters", "false");
-		return std::make_unique<GS::VTM::VocalTractModel4<float, 1>>(cfg, false);
+		return std::make_unique<GS::VTM::VocalTractModel4<float, 1>>(cfg, interactive);
 	}
 	if (model == "5f") {
 		cfg.put("model", "5");
 		cfg.put("log_parameters", "false");
-		return std::make_unique<GS::VTM::VocalTractModel5<float, 1>>(cfg, false);
+		return std::make_unique<GS::VTM::VocalTractModel5<float, 1>>(cfg, interactive);
 	}
 	if (model.rfind("2000:", 0) == 0) {
 		cfg.put("model", "2000");
 		cfg.put("dll_path", model.c_str() + 5);
-		return VocalTractModel::getInstance(cfg);
+		return VocalTractModel::getInstance(cfg, interactive);
 	}
 	cfg.put("model", model.c_str());
 	cfg.put("log_parameters", "false");
-	return VocalTractModel::getInstance(cfg);
+	return VocalTractModel::getInstance(cfg, interactive);
 }
 
 int main(int argc, char** argv)
@@ -106,6 +114,7 @@ int main(int argc, char** argv)
 		const double controlRate = std::atof(argv[4]);
 		const std::size_t nFrames = std::strtoul(argv[6], nullptr, 10);
 		const int repeat = argc > 8 ? std::atoi(argv[8]) : 1;
+		const std::size_t pollFrames = (argc > 9 && std::strncmp(argv[9], "poll=", 5) == 0) ? std::strtoul(argv[9] + 5, nullptr, 10) : 0;
 		const std::size_t numParam = 16;
 
 		std::vector<std::vector<float>> frames(nFrames, std::vector<float>(numParam));
@@ -121,7 +130,64 @@ int main(int argc, char** argv)
 			std::fclose(f);
 		}
 
-		auto vtm = make_model(cfg, model);
+		auto vtm = make_model(cfg, model, pollFrames > 0);
+
+		if (pollFrames > 0) {
+			// the per-step parameter vectors of the driver loop (Controller.cpp:294-311), handed over one by one
+			std::vector<std::vector<float>> stepParams;
+			if (!frames.empty()) {
+				std::vector<std::vector<float>> list = frames;
+				list.push_back(list.back());
+				const unsigned int controlSteps = static_cast<unsigned int>(std::rint(vtm->internalSampleRate() / controlRate));
+				const float coef = 1.0f / controlSteps;
+				std::vector<float> cur(numParam), delta(numParam);
+				for (std::size_t i = 1, size = list.size(); i < size; ++i) {
+					for (std::size_t j = 0; j < numParam; ++j) {
+						cur[j] = list[i - 1][j];
+						delta[j] = (list[i][j] - cur[j]) * coef;
+					}
+					for (std::size_t j = 0; j < controlSteps; ++j) {
+						stepParams.push_back(cur);
+						for (std::size_t k = 0; k < numParam; ++k) cur[k] += delta[k];
+					}
+				}
+			}
+			std::vector<float> drained, callback(pollFrames);
+			std::vector<float>& buffer = vtm->outputBuffer();
+			std::size_t bufferPos = 0, next = 0, callbacks = 0;
+			const auto t0 = std::chrono::steady_clock::now();
+			bool finished = false;
+			for (;;) {
+				// one JACK process() call (InteractiveAudio.cpp:141-204)
+				++callbacks;
+				std::size_t n = GS::VTM::Util::getSamples(buffer, bufferPos, callback.data(), pollFrames, 1.0f);
+				drained.insert(drained.end(), callback.begin(), callback.begin() + n);
+				if (n == pollFrames) continue;
+				if (finished) break; // nothing more will come
+				const std::size_t target = pollFrames - n;
+				while (buffer.size() < target && next < stepParams.size()) {
+					for (std::size_t i = 0; i < numParam; ++i) vtm->setParameter(static_cast<int>(i), stepParams[next][i]);
+					vtm->execSynthesisStep();
+					++next;
+				}
+				if (buffer.size() < target) {
+					vtm->finishSynthesis();
+					finished = true;
+				}
+				const std::size_t n2 = GS::VTM::Util::getSamples(buffer, bufferPos, callback.data(), target, 1.0f);
+				drained.insert(drained.end(), callback.begin(), callback.begin() + n2);
+			}
+			const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			if (std::strcmp(argv[7], "-") != 0) {
+				FILE* f = std::fopen(argv[7], "wb");
+				if (!f) { std::perror(argv[7]); return 2; }
+				std::fwrite(drained.data(), sizeof(float), drained.size(), f);
+				std::fclose(f);
+			}
+			std::printf("N=%zu steps=%zu fs=%.17g sec=%.6f ns_per_step=%.2f callbacks=%zu\n",
+					drained.size(), stepParams.size(), vtm->internalSampleRate(), sec, stepParams.empty() ? 0.0 : sec * 1e9 / stepParams.size(), callbacks);
+			return 0;
+		}
 
 		std::size_t steps = 0;
 		const auto t0 = std::chrono::steady_clock::now();

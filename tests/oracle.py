@@ -318,8 +318,10 @@ def ref_binary(kind="gold"):
 
 
 def ref_synthesize(params, model="0", output_rate=44100, control_rate=250, config=VOICE_MALE, kind="gold",
-                   repeat=1, tmpdir=None):
-    """Run the compiled reference on float32 frames; returns (audio float32, info dict)."""
+                   repeat=1, tmpdir=None, poll=0):
+    """Run the compiled reference on float32 frames; returns (audio float32, info dict).
+    poll > 0: the interactive caller contract (model constructed with interactive = true, outputBuffer() polled and
+    drained the way the editor's JACK callback does, `poll` samples per callback; oracle/ref_driver.cpp)."""
     import tempfile
     exe = ref_binary(kind)
     if exe is None:
@@ -330,7 +332,8 @@ def ref_synthesize(params, model="0", output_rate=44100, control_rate=250, confi
         pout = os.path.join(td, "o.f32")
         params.tofile(pin)
         r = subprocess.run([exe, config, str(model), repr(float(output_rate)), repr(float(control_rate)), pin,
-                            str(params.shape[0]), pout, str(repeat)], capture_output=True, text=True)
+                            str(params.shape[0]), pout, str(repeat)] + (["poll=%d" % poll] if poll else []),
+                           capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("ref_vtm failed: " + r.stderr)
         info = dict(kv.split("=") for kv in r.stdout.split())

@@ -70,6 +70,49 @@ def test_plugin_thirty_section_tube_through_reference_loader(golden, tmp_path):
     assert _within(out, ref, 1e-9), _peak_err(out, ref)
 
 
+@pytest.mark.skipif(oracle.ref_binary() is None, reason="oracle/_ref/ref_vtm (the compiled reference) not present")
+@pytest.mark.parametrize("poll", [64, 1024])
+@pytest.mark.parametrize("precision,name", [("f64", "hello_m0"), ("f32", "rand5_m1")])
+def test_plugin_interactive_protocol_through_reference_loader(precision, name, poll, golden, tmp_path):
+    """interactive = true (VocalTractModelPlugin.cpp:87): the reference's loader constructs our object for the editor's
+    caller contract, and the driver polls outputBuffer() after every execSynthesisStep() the way the JACK callback does
+    (InteractiveAudio.cpp:141-185; oracle/ref_driver.cpp `poll=`).  The drained samples must be the batch protocol's."""
+    keys = oracle.read_config_file(oracle.VOICE_MALE)
+    keys["gpu_precision"] = precision
+    cfg = str(tmp_path / "vtm_i.txt")
+    with open(cfg, "w") as f:
+        for k, v in keys.items():
+            f.write("%s = %s\n" % (k, v))
+    import golden_cases
+    case = next(c for c in golden_cases.CASES if c["name"] == name)
+    tr = golden_cases.track_for(case, golden)
+    out, info = oracle.ref_synthesize(tr, "2000:" + PLUGIN, config=cfg, tmpdir=str(tmp_path), poll=poll)
+    ref = golden[name + "__out"]
+    assert out.size == ref.size == int(info["N"]) and int(info["callbacks"]) >= ref.size // poll
+    if precision == "f32":
+        assert np.array_equal(out, ref)
+    else:
+        from test_gpu_parity import _within, _peak_err
+        assert _within(out, ref, 1e-9), _peak_err(out, ref)
+    # and the same samples as our own batch protocol, bit for bit
+    batch, _ = oracle.ref_synthesize(tr, "2000:" + PLUGIN, config=cfg, tmpdir=str(tmp_path))
+    assert np.array_equal(out, batch)
+
+
+@pytest.mark.skipif(oracle.ref_binary() is None, reason="oracle/_ref/ref_vtm (the compiled reference) not present")
+def test_plugin_consecutive_utterances_through_reference_loader(golden, tmp_path):
+    """Two syntheses on one plugin object, reset() in between as Controller does (Controller.cpp:231): the second
+    utterance must not inherit anything from the first (recorded steps, failure flags)."""
+    import golden_cases
+    case = next(c for c in golden_cases.CASES if c["name"] == "rand5_m0")
+    tr = golden_cases.track_for(case, golden)
+    out, info = oracle.ref_synthesize(tr, "2000:" + PLUGIN, tmpdir=str(tmp_path), repeat=3)
+    ref = golden["rand5_m0__out"]
+    assert out.size == ref.size
+    from test_gpu_parity import _within, _peak_err
+    assert _within(out, ref, 1e-9), _peak_err(out, ref)
+
+
 def _make_voice_dir(root, model="0"):
     keys = oracle.read_config_file(oracle.VOICE_MALE)
     keys["model"] = model
