@@ -47,3 +47,12 @@ def golden_overrun():
     data = {k: z[k] for k in z.files}
     data["manifest"] = json.loads(bytes(data.pop("manifest_json")).decode())
     return data
+
+
+@pytest.fixture(scope="session")
+def golden_wav():
+    """16-bit WAV files written by the reference's Controller::synthesizeToFile (tests/golden/make_wav_golden.py)."""
+    z = np.load(os.path.join(HERE, "golden", "wav_golden.npz"), allow_pickle=False)
+    data = {k: z[k] for k in z.files}
+    data["manifest"] = json.loads(bytes(data.pop("manifest_json")).decode())
+    return data

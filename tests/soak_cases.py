@@ -15,6 +15,7 @@ CASES = [  # name, delay, layout, precision, float_model, rate
     ("model2f_d2_float", 2, 0, capi.PRECISION_F32, 1, 44100.0),
     ("model2f_d3_float_48k", 3, 0, capi.PRECISION_F32, 1, 48000.0),
     ("model4f_float", 1, 1, capi.PRECISION_F32, 1, 44100.0),
+    ("model2f_d2_float_22k", 2, 0, capi.PRECISION_F32, 1, 22050.0),  # flush overruns at 18, 79, 567 ... frames
     ("model0_double", 1, 0, capi.PRECISION_F64, 0, 44100.0),
     ("model3_double", 3, 0, capi.PRECISION_F64, 0, 44100.0),
     ("model4_double_22k", 1, 1, capi.PRECISION_F64, 0, 22050.0),

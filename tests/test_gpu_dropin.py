@@ -113,9 +113,11 @@ def test_plugin_consecutive_utterances_through_reference_loader(golden, tmp_path
     assert _within(out, ref, 1e-9), _peak_err(out, ref)
 
 
-def _make_voice_dir(root, model="0"):
+def _make_voice_dir(root, model="0", rate=None):
     keys = oracle.read_config_file(oracle.VOICE_MALE)
     keys["model"] = model
+    if rate is not None:
+        keys["output_rate"] = repr(float(rate))
     os.makedirs(os.path.join(root, "variant"))
     variant_keys = ("vocal_tract_length", "glottal_pulse_tp", "glottal_pulse_tn_min", "glottal_pulse_tn_max",
                     "reference_glottal_pitch", "breathiness", "aperture_radius", "intonation_factor")
@@ -168,9 +170,46 @@ def test_batched_vtm_cli_writes_reference_wavs(model, layout, golden, tmp_path):
         assert pcm.size == ref.size
         scaled = (ref * np.float32(oracle.output_scale(ref))) * np.float32(32767.0)
         want = (np.sign(scaled) * np.floor(np.abs(scaled) + np.float32(0.5))).astype(np.int32)
-        assert np.abs(pcm.astype(np.int32) - want).max() <= 1
-        assert np.mean(pcm.astype(np.int32) == want) > 0.999
+        if model == "1":
+            # the float model's float32 samples are bit-identical to the reference's, hence the 16-bit stream is too
+            assert np.array_equal(pcm.astype(np.int32), want)
+        else:
+            # fp64 path: a sample may differ from the reference's by one float32 ulp (tests/test_gpu_parity.py), which
+            # can move a value across a rounding boundary: at most one LSB, on a handful of samples
+            assert np.abs(pcm.astype(np.int32) - want).max() <= 1
+            assert np.count_nonzero(pcm.astype(np.int32) != want) <= max(2, pcm.size // 10000)
     assert np.abs(_read_wav(os.path.join(out_dir, "hello.wav"))[1]).max() == 31129  # round(0.95 * 32767)
+
+
+@pytest.mark.parametrize("name", ["hello_m1_48k", "hello_m1_44k", "short40_m1_44k", "hello_m0_48k", "hello_m0_44k", "hello_m4_44k"])
+def test_batched_vtm_cli_against_wavs_the_reference_wrote(name, golden, golden_wav, tmp_path):
+    """SURVEY.md 8(a) row a16 pinned to the reference: the fixture is the WAV `gama_tts vtm` itself wrote for the
+    captured "Hello world" frames (Controller::synthesizeToFile -> writeOutputToFile -> WAVEFileWriter,
+    tests/golden/make_wav_golden.py).  Float model: the whole FILE byte for byte.  Double models: header identical,
+    samples within one LSB on at most 0.01 % of them."""
+    m = golden_wav["manifest"][name]
+    want_bytes = bytes(golden_wav[name + "__wav"])
+    voice = str(tmp_path / "voice")
+    _make_voice_dir(voice, m["model"], m["output_rate"])
+    out_dir = str(tmp_path / "out")
+    os.makedirs(out_dir)
+    tr = np.asarray(golden["hello_params"])[: m["frames"]]
+    p = str(tmp_path / "utt.txt")
+    with open(p, "w") as f:
+        for row in tr:
+            f.write(" ".join("%.9g" % v for v in row) + "\n")
+    r = subprocess.run([CLI, voice, out_dir, p], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got_bytes = open(os.path.join(out_dir, "utt.wav"), "rb").read()
+    assert len(got_bytes) == len(want_bytes) == m["bytes"]
+    assert got_bytes[:44] == want_bytes[:44]  # RIFF / fmt / data headers
+    if m["model"] == "1":
+        assert got_bytes == want_bytes
+    else:
+        got = np.frombuffer(got_bytes[44:], dtype="<i2").astype(np.int32)
+        want = np.frombuffer(want_bytes[44:], dtype="<i2").astype(np.int32)
+        assert np.abs(got - want).max() <= 1
+        assert np.count_nonzero(got != want) <= max(2, got.size // 10000)
 
 
 def test_batched_cli_shards_across_device_slots(golden, tmp_path):

@@ -15,8 +15,8 @@ def test_reduced_soak_every_model():
         assert s["wrong_counts"] == 0, (name, s)
         assert s["pass"], (name, s)
         assert s["frame_counts_lowered"] == 0
-    # the down-sampling cases really contained overrun lengths
-    for name in ("model2f_d3_float_48k", "model4f_float", "model3_double", "model4_double_22k", "model5_double"):
+    # these two really contained overrun lengths (the 44.1 / 48 kHz voices overrun at 2334+ frames: tests/test_gpu_overrun.py)
+    for name in ("model2f_d2_float_22k", "model4_double_22k"):
         assert res[name]["flush_overrun_utterances"] >= 1, (name, res[name])
-    for name in ("model1_float", "model2f_d2_float", "model2f_d3_float_48k", "model4f_float"):
+    for name in ("model1_float", "model2f_d2_float", "model2f_d3_float_48k", "model4f_float", "model2f_d2_float_22k"):
         assert res[name]["bit_identical_utterances"] == res[name]["utterances"], (name, res[name])

@@ -139,3 +139,40 @@ def test_oracle_matches_reference_at_flush_overrun_lengths(case, golden_overrun)
         assert np.array_equal(out[:: golden_cases.DIGEST_STRIDE], golden_overrun[case["name"] + "__strided"])
         assert np.array_equal(out[-golden_cases.OVERRUN_TAIL:], golden_overrun[case["name"] + "__tail"])
         assert np.abs(out[-600:]).max() > 0  # the extra lap is not silence
+
+
+def _wav_fields(data):
+    import struct
+    assert data[:4] == b"RIFF" and data[8:16] == b"WAVEfmt " and data[36:40] == b"data"
+    riff_len = struct.unpack("<I", data[4:8])[0]
+    fmt = struct.unpack("<IHHIIHH", data[16:36])
+    n = struct.unpack("<I", data[40:44])[0]
+    assert riff_len == len(data) - 8 and n == len(data) - 44
+    return fmt, np.frombuffer(data[44:], dtype="<i2")
+
+
+def pcm16_like_the_reference(x):
+    """Controller::writeOutputToFile (Controller.cpp:315-328): scale = 0.95 / max|x| (float), sample * scale (float);
+    WAVEFileWriter::writeSample (WAVEFileWriter.cpp:122-125): std::round(v * 32767.0f) to int16."""
+    scale = np.float32(oracle.output_scale(x))
+    v = (x * scale) * np.float32(32767.0)
+    return (np.sign(v) * np.floor(np.abs(v) + np.float32(0.5))).astype(np.int16)
+
+
+@pytest.mark.parametrize("name", ["hello_m0_48k", "hello_m1_48k", "hello_m0_44k", "hello_m1_44k", "short40_m1_44k", "hello_m4_44k"])
+def test_reference_written_wav(name, golden, golden_wav):
+    """N, WAV header and int16 samples of the reference's own `gama_tts vtm` run on the captured
+    "Hello world" frames.  Pins the oracle AND the restatement of the scaling / rounding rule bit for bit."""
+    m = golden_wav["manifest"][name]
+    data = bytes(golden_wav[name + "__wav"])
+    assert hashlib.sha256(data).hexdigest() == m["sha256"]
+    fmt, pcm = _wav_fields(data)
+    rate = int(m["output_rate"])
+    assert fmt == (16, 1, 1, rate, rate * 2, 2, 16)  # PCM, mono, 16 bit
+    tr = np.asarray(golden["hello_params"])[: m["frames"]]
+    layout = 1 if m["model"] == "4" else 0
+    cfg = oracle.male_config(m["output_rate"], 1, layout, float_model=int(m["model"] == "1"))
+    x = oracle.synthesize(cfg, tr)
+    assert pcm.size == x.size
+    assert np.array_equal(pcm16_like_the_reference(x), pcm)
+    assert np.abs(pcm).max() == 31129  # round(0.95 * 32767)
