@@ -108,7 +108,8 @@ def load_library(diagnostics=False):
     which adds the gvtm_debug_* hooks (tests and tools only; the product library exports none of them)."""
     if diagnostics in _libs:
         return _libs[diagnostics]
-    path = library_path(True) if diagnostics else (os.environ.get("GVTM_LIBRARY") or library_path())
+    # GVTM_LIBRARY / GVTM_DIAG_LIBRARY: A/B runs of library variants (tools/ab.py, tools/build_variant.sh)
+    path = (os.environ.get("GVTM_DIAG_LIBRARY") or library_path(True)) if diagnostics else (os.environ.get("GVTM_LIBRARY") or library_path())
     # libgama_vtm.so and PyTorch-ROCm both need libamdhip64.so.7 and a process can hold only one
     # copy: whichever loads first serves both.  PyTorch only works with the copy bundled in its
     # wheel, so when torch is installed let it load first (bench.py/tests share device pointers

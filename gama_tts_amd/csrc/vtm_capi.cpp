@@ -574,6 +574,15 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	args.maxabs = d_maxabs;
 	args.wavetable = plan->d_wavetable;
 	args.fir = plan->d_fir;
+	std::memset(&args.fir_k, 0, sizeof(args.fir_k));
+	if (!model5) {
+		const gvtm::Design& dg = plan->design;
+		if (dg.f32) {
+			for (size_t i = 0; i < dg.fir_f.size() && i < 64; ++i) args.fir_k.f[i] = dg.fir_f[i];
+		} else {
+			for (size_t i = 0; i < dg.fir.size() && i < 49; ++i) args.fir_k.d[i] = dg.fir[i];
+		}
+	}
 	args.src_h = plan->d_src_h;
 	args.src_dh = plan->d_src_dh;
 	args.max_frames = max_frames;

@@ -52,6 +52,9 @@ struct SynthArgs {
 	float* maxabs;               // [batch] or null
 	const void* wavetable;       // [512]      design tables: double, or float for GVTM_PRECISION_F32
 	const void* fir;             // [fir_taps]
+	// the same coefficients by value: kernel arguments are read with scalar loads, so the decimator's unrolled tap loop
+	// takes them from SGPRs (d: the double design, f: the float design of GVTM_PRECISION_F32)
+	union FirByValue { double d[49]; float f[64]; } fir_k;
 	const void* src_h;           // [3328]
 	const void* src_dh;          // [3328]
 	size_t max_frames;

@@ -35,7 +35,7 @@ for rep in range(2):
 cyc = d_cyc.cpu().numpy().astype(np.float64)
 steps = frames * plan.info.control_steps
 names = ["T tube", "S scan", "F1 pre-tube", "F2 post-tube", "I interp", "H0", "H1", "H2",
-         "stage P2a", "stage P2b", "stage P2c", "stage P4a", "stage P4b", "stage P6", "-", "-"]
+         "stage P2a", "stage P2b", "stage P2c", "stage P4a", "stage P4b", "stage P6", "T prologue", "T loop"]
 print("batch %d frames %d prec %d delay %d: kernel %.3f ms = %.1f ns/step" % (batch, frames, prec, delay, ms, ms * 1e6 / steps))
 for i, nm in enumerate(names):
     if cyc[:, i].max() > 0:
