@@ -91,6 +91,7 @@ struct gvtm_plan {
 	void* d_fir = nullptr;
 	void* d_src_h = nullptr;
 	void* d_src_dh = nullptr;
+	void* d_src_coef = nullptr; // polyphase coefficient table of up-sampling plans in the double precisions
 	gvtm::DeviceConstants* d_consts = nullptr;
 	gvtm::Model5Constants* d_consts5 = nullptr; // model 5 plans only
 	// staging for the host-buffer entry point
@@ -128,6 +129,7 @@ void free_plan(gvtm_plan* p)
 	if (p->d_fir) (void) hipFree(p->d_fir);
 	if (p->d_src_h) (void) hipFree(p->d_src_h);
 	if (p->d_src_dh) (void) hipFree(p->d_src_dh);
+	if (p->d_src_coef) (void) hipFree(p->d_src_coef);
 	if (p->d_consts) (void) hipFree(p->d_consts);
 	if (p->d_consts5) (void) hipFree(p->d_consts5);
 	p->s_params.release();
@@ -213,6 +215,8 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 			if ((e = upload(&plan->d_fir, dg.fir)) != hipSuccess) return fail_hip(e, "upload fir");
 			if ((e = upload(&plan->d_src_h, dg.src_h)) != hipSuccess) return fail_hip(e, "upload src_h");
 			if ((e = upload(&plan->d_src_dh, dg.src_dh)) != hipSuccess) return fail_hip(e, "upload src_dh");
+			if (!dg.src_coef_f.empty() && (e = upload(&plan->d_src_coef, dg.src_coef_f)) != hipSuccess) return fail_hip(e, "upload src coefficients");
+			if (!dg.src_coef_d.empty() && (e = upload(&plan->d_src_coef, dg.src_coef_d)) != hipSuccess) return fail_hip(e, "upload src coefficients");
 		}
 		if ((e = upload(&plan->d_consts, std::vector<gvtm::DeviceConstants>(1, plan->design.k))) != hipSuccess) return fail_hip(e, "upload constants");
 		*plan_out = plan.release();
@@ -551,6 +555,8 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 	int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows, k.section_delay);
 	if (sl && sl->rows == 1) rows = 1;
+	// four utterances in double keep no resampler table in LDS (the plan's coefficient table serves them): up-sampling only
+	if (!model5 && rows == 4 && plan->precision != GVTM_PRECISION_F32 && !plan->d_src_coef) rows = 2;
 	const int xr_fixed = sl ? sl->xr : 0;
 	// a shape whose rings do not fit (down-sampling plans carry the reference's 1024-sample ring per row) gives way to
 	// the next smaller one
@@ -585,6 +591,8 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	}
 	args.src_h = plan->d_src_h;
 	args.src_dh = plan->d_src_dh;
+	args.src_coef = plan->d_src_coef;
+	args.src_period_mask = plan->design.src_period ? plan->design.src_period - 1 : 0;
 	args.max_frames = max_frames;
 	args.audio_stride = audio_stride;
 	args.batch = batch;

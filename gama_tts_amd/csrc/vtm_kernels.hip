@@ -66,8 +66,10 @@ struct V2Shape {
 #ifdef GVTM_TUNE_C1
 	static constexpr int C = (U_ == 1) ? GVTM_TUNE_C1 : (U_ == 2 ? GVTM_TUNE_C2 : GVTM_TUNE_C4);
 #else
+	// four rows in double: 32 steps = two FULL 64-item passes per stage (24 steps left the second pass half empty and
+	// made every pass a large share of a tick); SectionDelay 3 unrolls the tube by 6 and keeps 24
 	static constexpr int C = (U_ == 1) ? (kAllFloat ? 144 : (kMixed ? 96 : 84))
-	                                   : (U_ == 2 ? (kAllFloat ? 96 : 48) : (U_ == 8 ? 24 : (kAllFloat ? 48 : 24)));
+	                                   : (U_ == 2 ? (kAllFloat ? 96 : 48) : (U_ == 8 ? 24 : (kAllFloat ? 48 : (D_ == 3 ? 24 : 32))));
 #endif
 #ifndef GVTM_TUNE_NH_MULTI
 #define GVTM_TUNE_NH_MULTI 7
@@ -118,6 +120,7 @@ static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t str
 	// (a stream keeps ONE ring length for all shapes, the one-row shape's: longer than this shape needs, never shorter)
 	if (args.xr < ring_length(args.k, S::C) || (args.xr & (args.xr - 1)) != 0 || 2 * S::C + 4 * args.k.pad > args.xr) return hipErrorInvalidValue;
 	if (!args.k.upsampling && args.xr != kSrcRing) return hipErrorInvalidValue;
+	if (v2::kSrcTable<CT, ST, U> && (!args.k.upsampling || args.src_coef == nullptr)) return hipErrorInvalidValue; // host picks rows <= 2 there
 	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C>(args.xr);
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
@@ -143,11 +146,12 @@ int synth_rows(int precision, size_t batch, int requested, int section_delay)
 	int rows = requested;
 	if (rows != 1 && rows != 2 && rows != 4 && rows != 8) {
 		rows = batch > 512 ? 4 : (batch > 256 ? 2 : 1);
-		// fp64: four rows fit since the resampler table lost its delta half, but measured no faster than two
-		// (9.2 vs 8.9 ms on batch 1024: the fp64 serial chains spill at 12 wavefronts per workgroup)
+		// (fp64 used to stop at two rows: with the compact records four fit with a chunk of 32 and run faster)
+#ifdef GVTM_TUNE_F64_ROWS2
 		if (precision == GVTM_PRECISION_F64 && rows > 2) rows = 2;
+#endif
 		// mixed with SectionDelay 3 or 4 (deeper fp64 delay lines per lane): measured 3.36 vs 2.63 and 2.07 vs 1.65 G samples/s
-		if (precision == GVTM_PRECISION_MIXED && section_delay >= 3 && rows > 2) rows = 2;
+		if (precision != GVTM_PRECISION_F32 && section_delay >= 3 && rows > 2) rows = 2;
 	}
 	return rows > max_rows ? max_rows : rows;
 }
@@ -155,32 +159,38 @@ int synth_rows(int precision, size_t batch, int requested, int section_delay)
 // what depends on the workgroup shape V2Shape picks: chunk length -> ring length -> LDS bytes
 struct ShapeNumbers { int chunk; size_t lds_fixed; size_t ring_elem; };
 
-template <typename CT, typename ST, int U>
+template <typename CT, typename ST, int U, int D>
 static ShapeNumbers v2_numbers()
 {
-	using S = V2Shape<CT, ST, U>;
+	using S = V2Shape<CT, ST, U, D>;
 	return ShapeNumbers{S::C, v2::smem_bytes<CT, ST, S::U, S::C>(0), sizeof(ST) * S::U};
 }
 
-template <typename CT, typename ST>
+template <typename CT, typename ST, int D>
 static ShapeNumbers v2_numbers_rows(int rows)
 {
 	if constexpr (sizeof(CT) == 4) {
-		if (rows == 8) return v2_numbers<CT, ST, 8>();
+		if (rows == 8) return v2_numbers<CT, ST, 8, D>();
 	}
-	return rows == 4 ? v2_numbers<CT, ST, 4>() : (rows == 2 ? v2_numbers<CT, ST, 2>() : v2_numbers<CT, ST, 1>());
+	return rows == 4 ? v2_numbers<CT, ST, 4, D>() : (rows == 2 ? v2_numbers<CT, ST, 2, D>() : v2_numbers<CT, ST, 1, D>());
 }
 
-static ShapeNumbers shape_numbers(int precision, int rows)
+static ShapeNumbers shape_numbers(int precision, int rows, int delay)
 {
-	if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float>(rows);
-	if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float>(rows);
-	return v2_numbers_rows<double, double>(rows);
+	// the chunk length depends on the SectionDelay only through "3 or not"
+	if (delay == 3) {
+		if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float, 3>(rows);
+		if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float, 3>(rows);
+		return v2_numbers_rows<double, double, 3>(rows);
+	}
+	if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float, 1>(rows);
+	if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float, 1>(rows);
+	return v2_numbers_rows<double, double, 1>(rows);
 }
 
 int synth_ring_length(const DeviceConstants& k, int precision, int rows)
 {
-	return ring_length(k, shape_numbers(precision, rows).chunk);
+	return ring_length(k, shape_numbers(precision, rows, k.section_delay).chunk);
 }
 
 size_t stream_state_bytes(const DeviceConstants& k, int precision, int xr)
@@ -193,7 +203,7 @@ size_t stream_state_bytes(const DeviceConstants& k, int precision, int xr)
 
 size_t synth_lds_bytes(const DeviceConstants& k, int precision, int rows, int xr)
 {
-	const ShapeNumbers n = shape_numbers(precision, rows);
+	const ShapeNumbers n = shape_numbers(precision, rows, k.section_delay);
 	return n.lds_fixed + ((n.ring_elem * static_cast<size_t>(xr > 0 ? xr : ring_length(k, n.chunk)) + 15) & ~size_t(15));
 }
 

@@ -57,6 +57,8 @@ struct SynthArgs {
 	union FirByValue { double d[49]; float f[64]; } fir_k;
 	const void* src_h;           // [3328]
 	const void* src_dh;          // [3328]
+	const void* src_coef = nullptr;  // [7][period][4] polyphase coefficients of an up-sampling plan (double precisions), or null
+	unsigned src_period_mask = 0;    // period - 1 (the period is a power of two)
 	size_t max_frames;
 	size_t audio_stride;
 	size_t batch;
