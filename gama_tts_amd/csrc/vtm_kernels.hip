@@ -93,7 +93,8 @@ static int ring_length(const DeviceConstants& k, int chunk)
 {
 	if (!k.upsampling) return kSrcRing;
 	int xr = 128;
-	while (xr < 2 * chunk + 4 * k.pad) xr *= 2;
+	// (+ 64: the resampler emits on a 64-aligned grid of outputs, so up to 63 outputs = at most 64 inputs wait a chunk longer)
+	while (xr < 2 * chunk + 4 * k.pad + 64) xr *= 2;
 	return xr;
 }
 
@@ -119,7 +120,7 @@ static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t str
 	constexpr int kWaves = v2::serial_waves<U, LAYOUT>() + NH;
 	auto fn = v2::vtm_synth_kernel<CT, ST, D, S::U, S::C, NH, LAYOUT>;
 	// (a stream keeps ONE ring length for all shapes, the one-row shape's: longer than this shape needs, never shorter)
-	if (args.xr < ring_length(args.k, S::C) || (args.xr & (args.xr - 1)) != 0 || 2 * S::C + 4 * args.k.pad > args.xr) return hipErrorInvalidValue;
+	if (args.xr < ring_length(args.k, S::C) || (args.xr & (args.xr - 1)) != 0 || 2 * S::C + 4 * args.k.pad + 64 > args.xr) return hipErrorInvalidValue;
 	if (!args.k.upsampling && args.xr != kSrcRing) return hipErrorInvalidValue;
 	if (v2::kSrcTable<CT, ST, U> && (!args.k.upsampling || args.src_coef == nullptr)) return hipErrorInvalidValue; // host picks rows <= 2 there
 	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C>(args.xr);
