@@ -337,6 +337,14 @@ int gvtm_debug_set_rows(gvtm_plan* plan, int rows)
 	return GVTM_OK;
 }
 
+/* LDS bytes of a workgroup of `rows` utterances of this plan's one-shot kernel (0 = model 5's). */
+size_t gvtm_debug_lds_bytes(const gvtm_plan* plan, int rows)
+{
+	if (!plan) return 0;
+	if (plan->design.model5) return gvtm::synth5_lds_bytes();
+	return gvtm::synth_lds_bytes(plan->design.k, plan->precision, rows, 0);
+}
+
 /* Test hook (not in the public header): device buffer [batch][max_frames*control_steps][8] of
  * doubles that receives per-step intermediate values of the next synthesis calls; null disables. */
 int gvtm_debug_set_taps(gvtm_plan* plan, double* d_taps)

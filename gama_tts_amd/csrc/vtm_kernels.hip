@@ -70,7 +70,9 @@ struct V2Shape {
 	// made every pass a large share of a tick); SectionDelay 3 unrolls the tube by 6 and keeps 24.  (28 steps for
 	// SectionDelay 1, so that the resampler's 61.6 outputs per chunk fill ONE pass, measured slower: 12.7 vs 13.3 G.)
 	static constexpr int C = (U_ == 1) ? (kAllFloat ? 144 : (kMixed ? 96 : 84))
-	                                   : (U_ == 2 ? (kAllFloat ? 96 : 48) : (U_ == 8 ? 24 : (kAllFloat ? 48 : (D_ == 3 ? 24 : 32))));
+	                                   : (U_ == 2 ? (kAllFloat ? 96 : 48) : (U_ == 8 ? 24 : (kAllFloat ? (D_ == 3 ? 36 : 48) : (D_ == 3 ? 24 : 32))));
+	// (float, four rows, SectionDelay 3: 36 -- reference model 3 down-samples to 44.1 kHz, so its rings are 1024 samples each,
+	// and with the lane-indexed tube record 48 steps no longer fit)
 #endif
 #ifndef GVTM_TUNE_NH_MULTI
 #define GVTM_TUNE_NH_MULTI 7
@@ -123,7 +125,7 @@ static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t str
 	if (args.xr < ring_length(args.k, S::C) || (args.xr & (args.xr - 1)) != 0 || 2 * S::C + 4 * args.k.pad + 64 > args.xr) return hipErrorInvalidValue;
 	if (!args.k.upsampling && args.xr != kSrcRing) return hipErrorInvalidValue;
 	if (v2::kSrcTable<CT, ST, U> && (!args.k.upsampling || args.src_coef == nullptr)) return hipErrorInvalidValue; // host picks rows <= 2 there
-	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C>(args.xr);
+	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C, v2::lane_rec<CT, LAYOUT>()>(args.xr);
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
 	if (e != hipSuccess) return e;
@@ -162,42 +164,43 @@ int synth_rows(int precision, size_t batch, int requested, int section_delay)
 struct ShapeNumbers { int chunk; size_t lds_fixed; size_t ring_elem; };
 
 template <typename CT, typename ST, int U, int D>
-static ShapeNumbers v2_numbers()
+static ShapeNumbers v2_numbers(int layout)
 {
 	using S = V2Shape<CT, ST, U, D>;
-	return ShapeNumbers{S::C, v2::smem_bytes<CT, ST, S::U, S::C>(0), sizeof(ST) * S::U};
+	const size_t lds = layout == 1 ? v2::smem_bytes<CT, ST, S::U, S::C, v2::lane_rec<CT, 1>()>(0) : v2::smem_bytes<CT, ST, S::U, S::C, v2::lane_rec<CT, 0>()>(0);
+	return ShapeNumbers{S::C, lds, sizeof(ST) * S::U};
 }
 
 template <typename CT, typename ST, int D>
-static ShapeNumbers v2_numbers_rows(int rows)
+static ShapeNumbers v2_numbers_rows(int rows, int layout)
 {
 	if constexpr (sizeof(CT) == 4) {
-		if (rows == 8) return v2_numbers<CT, ST, 8, D>();
+		if (rows == 8) return v2_numbers<CT, ST, 8, D>(layout);
 	}
-	return rows == 4 ? v2_numbers<CT, ST, 4, D>() : (rows == 2 ? v2_numbers<CT, ST, 2, D>() : v2_numbers<CT, ST, 1, D>());
+	return rows == 4 ? v2_numbers<CT, ST, 4, D>(layout) : (rows == 2 ? v2_numbers<CT, ST, 2, D>(layout) : v2_numbers<CT, ST, 1, D>(layout));
 }
 
-static ShapeNumbers shape_numbers(int precision, int rows, int delay)
+static ShapeNumbers shape_numbers(int precision, int rows, int delay, int layout)
 {
 	// the chunk length depends on the SectionDelay through "1, 3 or another"
 	if (delay == 3) {
-		if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float, 3>(rows);
-		if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float, 3>(rows);
-		return v2_numbers_rows<double, double, 3>(rows);
+		if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float, 3>(rows, layout);
+		if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float, 3>(rows, layout);
+		return v2_numbers_rows<double, double, 3>(rows, layout);
 	}
 	if (delay != 1) {
-		if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float, 2>(rows);
-		if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float, 2>(rows);
-		return v2_numbers_rows<double, double, 2>(rows);
+		if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float, 2>(rows, layout);
+		if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float, 2>(rows, layout);
+		return v2_numbers_rows<double, double, 2>(rows, layout);
 	}
-	if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float, 1>(rows);
-	if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float, 1>(rows);
-	return v2_numbers_rows<double, double, 1>(rows);
+	if (precision == GVTM_PRECISION_F32) return v2_numbers_rows<float, float, 1>(rows, layout);
+	if (precision == GVTM_PRECISION_MIXED) return v2_numbers_rows<double, float, 1>(rows, layout);
+	return v2_numbers_rows<double, double, 1>(rows, layout);
 }
 
 int synth_ring_length(const DeviceConstants& k, int precision, int rows)
 {
-	return ring_length(k, shape_numbers(precision, rows, k.section_delay).chunk);
+	return ring_length(k, shape_numbers(precision, rows, k.section_delay, k.layout).chunk);
 }
 
 size_t stream_state_bytes(const DeviceConstants& k, int precision, int xr)
@@ -210,7 +213,7 @@ size_t stream_state_bytes(const DeviceConstants& k, int precision, int xr)
 
 size_t synth_lds_bytes(const DeviceConstants& k, int precision, int rows, int xr)
 {
-	const ShapeNumbers n = shape_numbers(precision, rows, k.section_delay);
+	const ShapeNumbers n = shape_numbers(precision, rows, k.section_delay, k.layout);
 	return n.lds_fixed + ((n.ring_elem * static_cast<size_t>(xr > 0 ? xr : ring_length(k, n.chunk)) + 15) & ~size_t(15));
 }
 

@@ -153,11 +153,10 @@ def test_plugin_library_exports_the_gamatts_symbols():
         assert hasattr(plugin, name), name
     plugin.GAMA_TTS_construct_vocal_tract_model.restype = ctypes.c_void_p
     plugin.GAMA_TTS_construct_vocal_tract_model.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    # interactive use (per-step polling) is refused: NULL -> the host raises
-    # "Could not construct the vocal tract model." (VocalTractModelPlugin.cpp:88-90)
-    dummy = ctypes.create_string_buffer(256)
-    assert plugin.GAMA_TTS_construct_vocal_tract_model(dummy, 1) is None
+    # a failed construct returns NULL -> the host raises "Could not construct the vocal tract model."
+    # (VocalTractModelPlugin.cpp:88-90); both caller contracts (batch and interactive) with no configuration
     assert plugin.GAMA_TTS_construct_vocal_tract_model(None, 0) is None
+    assert plugin.GAMA_TTS_construct_vocal_tract_model(None, 1) is None
     assert os.access(os.path.join(libdir, "gama_vtm_batch"), os.X_OK)
 
 
