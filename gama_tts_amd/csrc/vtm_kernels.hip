@@ -59,8 +59,8 @@ struct V2Shape {
 	//   U > 1: every tick has fixed costs (barrier, stage prologues, ticket traffic, partly filled 64-item
 	//          passes), so the longest chunk LDS allows wins: measured on batch 4096 in float, C = 24 / 36 / 48
 	//          -> 24.8 / 21.6 / 18.4 ms; batch 512, C = 24 / 48 / 96 -> 4.71 / 4.64 / 4.38 ms.
-	// LDS per workgroup (KB): float 1x144 118, 2x96 143, 4x48 144; mixed 1x96 132, 2x48 131, 4x24 138;
-	// fp64 1x84 148, 2x48 135 and 4x24 146 (resampler table without its delta half).
+	// LDS per workgroup: tests/tools/lds_sizes.py (float 1x144 120 KB, 2x96 152, 4x48 154; mixed 4x32 154; fp64 4x32 159).
+	// (fp64 with several rows: resampler table without its delta half)
 	static constexpr bool kAllFloat = sizeof(CT) == 4;
 	static constexpr bool kMixed = sizeof(CT) == 8 && sizeof(ST) == 4;
 #ifdef GVTM_TUNE_C1
