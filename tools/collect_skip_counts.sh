@@ -10,7 +10,7 @@ for v in none 1 2 4 8 16 32 64 128 256 512 1024 2047; do
   if [ $v = none ]; then unset GVTM_LIBRARY; else export GVTM_LIBRARY=gama_tts_amd/lib_variants/libgama_vtm_skip$v.so; fi
   d=gpurun_out/${tag}_skip_$v
   rm -rf $d
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $d -- python3 bench.py --precision $prec --batch 4096 --frames 500 --delay $delay --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $d.log 2>&1
+  rocprofv3 --kernel-trace --pmc ${GVTM_SKIP_COUNTERS:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE} --output-format csv -d $d -- python3 bench.py --precision $prec --batch 4096 --frames 500 --delay $delay --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $d.log 2>&1
   python3 - "$d" "$v" >> $out <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
