@@ -407,7 +407,7 @@ int gvtm_debug_short_math(int kind, const double* x, size_t n, double* out)
  * kernel on the plan's device (kind 0..3), host arrays in and out. */
 int gvtm_debug_device_float_math(gvtm_plan* plan, int kind, const float* x, size_t n, float* out)
 {
-	if (!plan || !x || !out || kind < 0 || kind > 3) return fail(GVTM_ERR_INVALID_ARGUMENT, "bad argument");
+	if (!plan || !x || !out || kind < 0 || kind > 4) return fail(GVTM_ERR_INVALID_ARGUMENT, "bad argument");
 	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan");
 	DeviceScope scope(plan->device);
 	hipError_t e = scope.status();

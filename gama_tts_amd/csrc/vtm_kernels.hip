@@ -286,6 +286,7 @@ __global__ void float_math_probe_kernel(int kind, const float* x, size_t n, floa
 	case 1: r = amplitude_60db_dev(v); break;
 	case 2: r = tan_dev(v); break;
 	case 3: r = cos_dev(v); break;
+	case 4: r = fdiv_n(v, x[i ^ 1]); break; // (n even)
 	}
 	out[i] = r;
 }
