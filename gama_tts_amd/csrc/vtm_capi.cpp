@@ -81,6 +81,10 @@ private:
 
 } // namespace
 
+#ifndef GVTM_NOISE_TABLE
+#define GVTM_NOISE_TABLE 1
+#endif
+
 struct gvtm_plan {
 	gvtm::Design design;
 	int device = 0;
@@ -92,6 +96,11 @@ struct gvtm_plan {
 	void* d_src_h = nullptr;
 	void* d_src_dh = nullptr;
 	void* d_src_coef = nullptr; // polyphase coefficient table of up-sampling plans in the double precisions
+	// the noise source's samples by internal step (the same for every utterance), grown on demand; superseded buffers stay
+	// allocated until the plan goes (a launch in flight on the caller's stream may still read them)
+	void* d_noise = nullptr;
+	size_t noise_len = 0;
+	std::vector<void*> noise_retired;
 	gvtm::DeviceConstants* d_consts = nullptr;
 	gvtm::Model5Constants* d_consts5 = nullptr; // model 5 plans only
 	// staging for the host-buffer entry point
@@ -130,6 +139,8 @@ void free_plan(gvtm_plan* p)
 	if (p->d_src_h) (void) hipFree(p->d_src_h);
 	if (p->d_src_dh) (void) hipFree(p->d_src_dh);
 	if (p->d_src_coef) (void) hipFree(p->d_src_coef);
+	if (p->d_noise) (void) hipFree(p->d_noise);
+	for (void* q : p->noise_retired) (void) hipFree(q);
 	if (p->d_consts) (void) hipFree(p->d_consts);
 	if (p->d_consts5) (void) hipFree(p->d_consts5);
 	p->s_params.release();
@@ -601,6 +612,27 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	args.src_dh = plan->d_src_dh;
 	args.src_coef = plan->d_src_coef;
 	args.src_period_mask = plan->design.src_period ? plan->design.src_period - 1 : 0;
+	if (!model5 && !sl && GVTM_NOISE_TABLE) {
+		// one-shot launches read the noise samples from the plan's table (streams generate them: their length has no bound)
+		const size_t steps = max_frames * static_cast<size_t>(k.control_steps);
+		if (steps > plan->noise_len) {
+			const size_t want = ((steps + (size_t(1) << 18) - 1) >> 18) << 18;
+			const bool f32 = plan->precision == GVTM_PRECISION_F32;
+			std::vector<unsigned char> host(want * (f32 ? sizeof(float) : sizeof(double)));
+			gvtm::design_noise_table(want, f32, host.data());
+			void* fresh = nullptr;
+			if ((e = hipMalloc(&fresh, host.size())) != hipSuccess) return fail_hip(e, "hipMalloc (noise table)");
+			if ((e = hipMemcpy(fresh, host.data(), host.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+				(void) hipFree(fresh);
+				return fail_hip(e, "hipMemcpy (noise table)");
+			}
+			if (plan->d_noise) plan->noise_retired.push_back(plan->d_noise);
+			plan->d_noise = fresh;
+			plan->noise_len = want;
+		}
+		args.noise_lp = plan->d_noise;
+		args.noise_len = plan->noise_len;
+	}
 	args.max_frames = max_frames;
 	args.audio_stride = audio_stride;
 	args.batch = batch;

@@ -355,6 +355,34 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 // device's for the precision (vtm_kernel_v2.inc, stage P6): mixed = float tables {h, dh} narrowed from the double design,
 // one fused multiply-add; fp64 = h with dh re-formed as h[i+1] - h[i] (as initializeFilter formed it), one fused
 // multiply-add.
+void design_noise_table(size_t n, bool as_float, void* out)
+{
+	// (this file is compiled with -ffp-contract=off: the product is rounded before its floor is subtracted, as in the
+	// reference and in the kernel's noise_advance)
+	double seed = 0.7892347; // NoiseSource.h:32-34
+	if (as_float) {
+		float* o = static_cast<float*>(out);
+		float prev = 0.0f;
+		for (size_t i = 0; i < n; ++i) {
+			const double product = seed * 377.0;
+			seed = product - std::floor(product);
+			const float white = static_cast<float>(seed - 0.5);
+			o[i] = white + prev;
+			prev = white;
+		}
+	} else {
+		double* o = static_cast<double*>(out);
+		double prev = 0.0;
+		for (size_t i = 0; i < n; ++i) {
+			const double product = seed * 377.0;
+			seed = product - std::floor(product);
+			const double white = seed - 0.5;
+			o[i] = white + prev;
+			prev = white;
+		}
+	}
+}
+
 void design_src_coefficients(Design& d)
 {
 	d.src_period = 0;

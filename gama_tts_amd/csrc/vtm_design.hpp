@@ -99,6 +99,10 @@ struct Design {
 
 // fills Design::src_coef_* (design_plan calls it)
 void design_src_coefficients(Design& d);
+// The noise source's low-passed samples for internal steps [0, n) (NoiseSource.h:40-44 with its fixed seed,
+// NoiseFilter.h:63-68): every utterance of every batch draws the same sequence after reset(), so a plan tabulates it
+// once; `out` holds n floats (as_float: the sum formed in float as NoiseFilter<float> does) or n doubles.
+void design_noise_table(size_t n, bool as_float, void* out);
 
 // Returns "" on success, otherwise a description of the offending value.
 std::string design_plan(const gvtm_config& cfg, double control_rate, Design& out);
