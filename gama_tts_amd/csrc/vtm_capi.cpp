@@ -356,6 +356,14 @@ size_t gvtm_debug_lds_bytes(const gvtm_plan* plan, int rows)
 	return gvtm::synth_lds_bytes(plan->design.k, plan->precision, rows, 0);
 }
 
+/* The plan-level noise-sample table as the host builds it (n floats or doubles); needs no device. */
+int gvtm_debug_noise_table(size_t n, int as_float, void* out)
+{
+	if (!out) return fail(GVTM_ERR_INVALID_ARGUMENT, "null buffer");
+	gvtm::design_noise_table(n, as_float != 0, out);
+	return GVTM_OK;
+}
+
 /* Test hook (not in the public header): device buffer [batch][max_frames*control_steps][8] of
  * doubles that receives per-step intermediate values of the next synthesis calls; null disables. */
 int gvtm_debug_set_taps(gvtm_plan* plan, double* d_taps)

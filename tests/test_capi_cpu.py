@@ -274,3 +274,42 @@ def test_header_is_plain_c_and_the_c_example_builds(tmp_path):
         assert "no HIP device" in r.stdout
     else:
         assert "utterance 1: 88108 samples" in r.stdout
+
+
+def test_noise_table_is_the_reference_sequence():
+    """The per-plan table of noise samples (csrc/vtm_design.cpp: design_noise_table) against a numpy restatement of
+    NoiseSource::getSample + NoiseFilter::filter (vtm/NoiseSource.h:40-44, vtm/NoiseFilter.h:63-68): seed 0.7892347,
+    seed = frac(seed * 377) with the product rounded first, sample seed - 0.5, y = x + x1 in TFloat."""
+    lib = g.load_library(diagnostics=True)
+    lib.gvtm_debug_noise_table.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    n = 100000
+    seed = np.float64(0.7892347)
+    white = np.empty(n, np.float64)
+    for i in range(n):
+        product = np.float64(seed * np.float64(377.0))
+        seed = np.float64(product - np.floor(product))
+        white[i] = seed - np.float64(0.5)
+    for as_float, dt in ((0, np.float64), (1, np.float32)):
+        w = white.astype(dt)
+        want = w.copy()
+        want[1:] = (w[1:] + w[:-1]).astype(dt)
+        got = np.empty(n, dt)
+        assert lib.gvtm_debug_noise_table(n, as_float, got.ctypes.data) == 0
+        assert np.array_equal(got.view(np.uint32 if as_float else np.uint64), want.view(np.uint32 if as_float else np.uint64))
+
+
+@pytest.mark.parametrize("precision", [capi.PRECISION_F64, capi.PRECISION_MIXED, capi.PRECISION_F32])
+def test_every_plan_has_a_workgroup_shape_that_fits_the_lds(precision):
+    """160 KB of LDS per workgroup: one utterance per workgroup must always fit (the launch falls back to it), and the
+    shapes the headline workloads use (four utterances per workgroup, up-sampling plans) must keep fitting."""
+    lib = g.load_library(diagnostics=True)
+    lib.gvtm_debug_lds_bytes.restype = ctypes.c_size_t
+    lib.gvtm_debug_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    cfgd = g.read_config_file(oracle.VOICE_MALE)
+    for delay in (1, 2, 3, 4):
+        for rate in (16000.0, 22050.0, 44100.0, 48000.0):
+            plan = g.Plan(g.config_from_dict(cfgd, rate, delay, precision), 250.0, -1, diagnostics=True)
+            assert lib.gvtm_debug_lds_bytes(plan._h, 1) <= 160 * 1024, (delay, rate)
+            upsampling = plan.info.upsampling
+            if upsampling and delay <= 2:
+                assert lib.gvtm_debug_lds_bytes(plan._h, 4) <= 160 * 1024, (delay, rate)
