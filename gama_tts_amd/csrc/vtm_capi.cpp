@@ -620,12 +620,12 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	args.src_dh = plan->d_src_dh;
 	args.src_coef = plan->d_src_coef;
 	args.src_period_mask = plan->design.src_period ? plan->design.src_period - 1 : 0;
-	if (!model5 && !sl && GVTM_NOISE_TABLE) {
+	if (!model5 && !sl && GVTM_NOISE_TABLE && plan->precision == GVTM_PRECISION_F32) {
 		// one-shot launches read the noise samples from the plan's table (streams generate them: their length has no bound)
 		const size_t steps = max_frames * static_cast<size_t>(k.control_steps);
 		if (steps > plan->noise_len) {
 			const size_t want = ((steps + (size_t(1) << 18) - 1) >> 18) << 18;
-			const bool f32 = plan->precision == GVTM_PRECISION_F32;
+			const bool f32 = true; // (the double paths generate the samples in the kernel: measured faster there)
 			std::vector<unsigned char> host(want * (f32 ? sizeof(float) : sizeof(double)));
 			gvtm::design_noise_table(want, f32, host.data());
 			void* fresh = nullptr;

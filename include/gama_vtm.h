@@ -217,8 +217,8 @@ size_t gvtm_output_capacity(const gvtm_plan* plan, size_t max_frames);
  *   d_out_counts   [batch] int64 samples per utterance, may be NULL
  *   d_maxabs       [batch] float32 max|x| per utterance, may be NULL
  *   hip_stream     hipStream_t (NULL = default stream); the call only enqueues work
- *                  (the first call of a plan, and a later one with more frames than any before, also builds and uploads
- *                  the plan's noise-sample table for max_frames frames: 4 or 8 bytes per internal step, synchronously)
+ *                  (GVTM_PRECISION_F32 plans: the first call, and a later one with more frames than any before, also builds
+ *                  and uploads the plan's noise-sample table for max_frames frames, 4 bytes per internal step, synchronously)
  */
 int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_counts,
 		size_t batch, size_t max_frames, float* d_audio, size_t audio_stride,
