@@ -32,4 +32,5 @@ python3 bench.py --model 5 --steps 10 --warmup 2 > $out/${tag}_bench_model5.json
 python3 bench.py --model 4 --steps 10 --warmup 2 --precision f64 > $out/${tag}_bench_model4.json 2> $out/${tag}_bench_model4.err
 python3 tests/tools/parity_report.py > $out/${tag}_config3_parity.json 2> $out/${tag}_config3_parity.err
 python3 tests/tools/bench_aux.py > $out/${tag}_bench_aux.json 2> $out/${tag}_bench_aux.err
+python3 tests/tools/bench_models.py > $out/${tag}_bench_models.txt 2> $out/${tag}_bench_models.err
 echo done

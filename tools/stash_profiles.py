@@ -19,7 +19,7 @@ def one(pattern):
     return hits[0] if hits else None
 
 
-for p in glob.glob(os.path.join(src, tag + "_*.json")) + glob.glob(os.path.join(src, tag + "_role_cycles_*.txt")):
+for p in glob.glob(os.path.join(src, tag + "_*.json")) + glob.glob(os.path.join(src, tag + "_role_cycles_*.txt")) + glob.glob(os.path.join(src, tag + "_bench_models.txt")) + glob.glob(os.path.join(src, tag + "_tick_trace.txt")):
     if os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, os.path.basename(p)))
 for p in ("f32", "mixed", "f64"):
