@@ -623,7 +623,10 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	if (!model5 && !sl && GVTM_NOISE_TABLE && plan->precision == GVTM_PRECISION_F32) {
 		// one-shot launches read the noise samples from the plan's table (streams generate them: their length has no bound)
 		const size_t steps = max_frames * static_cast<size_t>(k.control_steps);
-		if (steps > plan->noise_len) {
+		constexpr size_t kNoiseTableMaxSteps = size_t(1) << 26; // 256 MB of table (~55 min of audio per utterance): beyond it the kernel generates the samples
+		if (steps > kNoiseTableMaxSteps) {
+			// (args.noise_lp stays null)
+		} else if (steps > plan->noise_len) {
 			const size_t want = ((steps + (size_t(1) << 18) - 1) >> 18) << 18;
 			const bool f32 = true; // (the double paths generate the samples in the kernel: measured faster there)
 			std::vector<unsigned char> host(want * (f32 ? sizeof(float) : sizeof(double)));
@@ -638,8 +641,10 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 			plan->d_noise = fresh;
 			plan->noise_len = want;
 		}
-		args.noise_lp = plan->d_noise;
-		args.noise_len = plan->noise_len;
+		if (steps <= kNoiseTableMaxSteps) {
+			args.noise_lp = plan->d_noise;
+			args.noise_len = plan->noise_len;
+		}
 	}
 	args.max_frames = max_frames;
 	args.audio_stride = audio_stride;
