@@ -95,7 +95,6 @@ struct gvtm_plan {
 	void* d_fir = nullptr;
 	void* d_src_h = nullptr;
 	void* d_src_dh = nullptr;
-	void* d_src_coef = nullptr; // polyphase coefficient table of up-sampling plans in the double precisions
 	// the noise source's samples by internal step (the same for every utterance), grown on demand; superseded buffers stay
 	// allocated until the plan goes (a launch in flight on the caller's stream may still read them)
 	void* d_noise = nullptr;
@@ -138,7 +137,6 @@ void free_plan(gvtm_plan* p)
 	if (p->d_fir) (void) hipFree(p->d_fir);
 	if (p->d_src_h) (void) hipFree(p->d_src_h);
 	if (p->d_src_dh) (void) hipFree(p->d_src_dh);
-	if (p->d_src_coef) (void) hipFree(p->d_src_coef);
 	if (p->d_noise) (void) hipFree(p->d_noise);
 	for (void* q : p->noise_retired) (void) hipFree(q);
 	if (p->d_consts) (void) hipFree(p->d_consts);
@@ -226,8 +224,6 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 			if ((e = upload(&plan->d_fir, dg.fir)) != hipSuccess) return fail_hip(e, "upload fir");
 			if ((e = upload(&plan->d_src_h, dg.src_h)) != hipSuccess) return fail_hip(e, "upload src_h");
 			if ((e = upload(&plan->d_src_dh, dg.src_dh)) != hipSuccess) return fail_hip(e, "upload src_dh");
-			if (!dg.src_coef_f.empty() && (e = upload(&plan->d_src_coef, dg.src_coef_f)) != hipSuccess) return fail_hip(e, "upload src coefficients");
-			if (!dg.src_coef_d.empty() && (e = upload(&plan->d_src_coef, dg.src_coef_d)) != hipSuccess) return fail_hip(e, "upload src coefficients");
 		}
 		if ((e = upload(&plan->d_consts, std::vector<gvtm::DeviceConstants>(1, plan->design.k))) != hipSuccess) return fail_hip(e, "upload constants");
 		*plan_out = plan.release();
@@ -339,6 +335,7 @@ size_t gvtm_output_capacity(const gvtm_plan* plan, size_t max_frames)
 
 #ifdef GVTM_DIAGNOSTICS
 /* ---- hooks of the diagnostics build (libgama_vtm_diag.so; tests and tools only, not in the public header) ---- */
+#pragma GCC visibility push(default)
 
 /* Forces the utterances per workgroup (1, 2, 4, 8; 0 = by batch size), i.e. the kernel shape a big batch would get. */
 int gvtm_debug_set_rows(gvtm_plan* plan, int rows)
@@ -443,6 +440,7 @@ int gvtm_debug_device_float_math(gvtm_plan* plan, int kind, const float* x, size
 	return GVTM_OK;
 }
 
+#pragma GCC visibility pop
 #endif /* GVTM_DIAGNOSTICS */
 
 size_t gvtm_tracks_frame_count(const gvtm_track_config* config, const gvtm_event* events, size_t n_events)
@@ -582,8 +580,6 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 	int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows, k.section_delay);
 	if (sl && sl->rows == 1) rows = 1;
-	// four utterances in double keep no resampler table in LDS (the plan's coefficient table serves them): up-sampling only
-	if (!model5 && rows == 4 && plan->precision != GVTM_PRECISION_F32 && !plan->d_src_coef) rows = 2;
 	const int xr_fixed = sl ? sl->xr : 0;
 	// a shape whose rings do not fit (down-sampling plans carry the reference's 1024-sample ring per row) gives way to
 	// the next smaller one
@@ -618,8 +614,6 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	}
 	args.src_h = plan->d_src_h;
 	args.src_dh = plan->d_src_dh;
-	args.src_coef = plan->d_src_coef;
-	args.src_period_mask = plan->design.src_period ? plan->design.src_period - 1 : 0;
 	if (!model5 && !sl && GVTM_NOISE_TABLE && plan->precision == GVTM_PRECISION_F32) {
 		// one-shot launches read the noise samples from the plan's table (streams generate them: their length has no bound)
 		const size_t steps = max_frames * static_cast<size_t>(k.control_steps);

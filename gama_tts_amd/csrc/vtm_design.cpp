@@ -345,16 +345,11 @@ std::string design_plan(const gvtm_config& c, double control_rate, Design& out)
 	const std::string msg = design_numbers<double>(c, control_rate, k, tb);
 	if (!msg.empty()) return msg;
 	out.fir = tb.fir; out.src_h = tb.src_h; out.src_dh = tb.src_dh; out.wavetable = tb.wavetable;
-	design_src_coefficients(out);
 	return "";
 }
 
-// The up-sampling loop of SampleRateConverter::dataEmpty (vtm/SampleRateConverter.h:311-360) forms, for output k with
-// time register t = k * inc: left wing taps h[l + 256 j] + dh[l + 256 j] * (m / 256) with l = bits 15..8 and m = bits
-// 7..0 of t, right wing the same from ~t.  Both depend on t mod 2^16 only, i.e. on k mod period.  The arithmetic is the
-// device's for the precision (vtm_kernel_v2.inc, stage P6): mixed = float tables {h, dh} narrowed from the double design,
-// one fused multiply-add; fp64 = h with dh re-formed as h[i+1] - h[i] (as initializeFilter formed it), one fused
-// multiply-add.
+// NoiseSource::getSample + NoiseFilter::filter (vtm/NoiseSource.h:40-44, vtm/NoiseFilter.h:63-68) for steps [0, n): the
+// generator is double whatever TFloat is; the one-zero low-pass adds in TFloat.
 void design_noise_table(size_t n, bool as_float, void* out)
 {
 	// (this file is compiled with -ffp-contract=off: the product is rounded before its floor is subtracted, as in the
@@ -379,43 +374,6 @@ void design_noise_table(size_t n, bool as_float, void* out)
 			const double white = seed - 0.5;
 			o[i] = white + prev;
 			prev = white;
-		}
-	}
-}
-
-void design_src_coefficients(Design& d)
-{
-	d.src_period = 0;
-	d.src_coef_f.clear();
-	d.src_coef_d.clear();
-	const DeviceConstants& k = d.k;
-	if (!k.upsampling || d.f32 || d.model5) return;
-	unsigned g = k.time_inc, b = 65536u;
-	while (b) { const unsigned t = g % b; g = b; b = t; }
-	const unsigned period = 65536u / g;
-	d.src_period = period;
-	const bool mixed = d.config.precision == GVTM_PRECISION_MIXED;
-	if (mixed) d.src_coef_f.assign(static_cast<size_t>(7) * period * 4, 0.0f);
-	else d.src_coef_d.assign(static_cast<size_t>(7) * period * 4, 0.0);
-	for (unsigned r = 0; r < period; ++r) {
-		const unsigned frac = static_cast<unsigned>((static_cast<unsigned long long>(r) * k.time_inc) & 0xFFFFu);
-		const unsigned nfrac = (~frac) & 0xFFFFu;
-		for (int wing = 0; wing < 2; ++wing) {
-			const unsigned f = wing ? nfrac : frac;
-			const unsigned l = f >> 8, m = f & 0xFFu;
-			for (int j = 0; j < kSrcZeroCrossings; ++j) {
-				const unsigned i = l + 256u * static_cast<unsigned>(j);
-				const int tap = wing * kSrcZeroCrossings + j;
-				const size_t at = (static_cast<size_t>(tap / 4) * period + r) * 4 + static_cast<size_t>(tap % 4);
-				if (mixed) {
-					const float h = static_cast<float>(d.src_h[i]), dh = static_cast<float>(d.src_dh[i]);
-					d.src_coef_f[at] = std::fma(dh, static_cast<float>(m) / 256.0f, h);
-				} else {
-					const double h = d.src_h[i];
-					const double dh = (i + 1 < static_cast<unsigned>(kSrcFilterLength) ? d.src_h[i + 1] : 0.0) - h;
-					d.src_coef_d[at] = std::fma(dh, static_cast<double>(m) / 256.0, h);
-				}
-			}
 		}
 	}
 }

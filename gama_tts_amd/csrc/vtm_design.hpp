@@ -90,15 +90,8 @@ struct Design {
 	// GVTM_PRECISION_F32: the tables as designed in float (the double vectors above hold the same values widened)
 	bool f32 = false;
 	std::vector<float> fir_f, src_h_f, src_dh_f, wavetable_f;
-	// up-sampling plans in the double precisions: the resampler's 26 polyphase coefficients per output phase,
-	// [7][period][4] (taps 0..12 = left wing, 13..25 = right wing, 2 unused), rounded as the kernel would form them
-	unsigned src_period = 0;
-	std::vector<float> src_coef_f;   // GVTM_PRECISION_MIXED
-	std::vector<double> src_coef_d;  // GVTM_PRECISION_F64
 };
 
-// fills Design::src_coef_* (design_plan calls it)
-void design_src_coefficients(Design& d);
 // The noise source's low-passed samples for internal steps [0, n) (NoiseSource.h:40-44 with its fixed seed,
 // NoiseFilter.h:63-68): every utterance of every batch draws the same sequence after reset(), so a plan tabulates it
 // once; `out` holds n floats (as_float: the sum formed in float as NoiseFilter<float> does) or n doubles.

@@ -124,19 +124,12 @@ static hipError_t launch_v2(const SynthArgs& args, size_t batch, hipStream_t str
 	// (a stream keeps ONE ring length for all shapes, the one-row shape's: longer than this shape needs, never shorter)
 	if (args.xr < ring_length(args.k, S::C) || (args.xr & (args.xr - 1)) != 0 || 2 * S::C + 4 * args.k.pad + 64 > args.xr) return hipErrorInvalidValue;
 	if (!args.k.upsampling && args.xr != kSrcRing) return hipErrorInvalidValue;
-	if (v2::kSrcTable<CT, ST, U> && (!args.k.upsampling || args.src_coef == nullptr)) return hipErrorInvalidValue; // host picks rows <= 2 there
 	const size_t lds = v2::smem_bytes<CT, ST, S::U, S::C, v2::lane_rec<CT, LAYOUT>()>(args.xr);
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
 			static_cast<int>(lds));
 	if (e != hipSuccess) return e;
 	const unsigned groups = static_cast<unsigned>((batch + S::U - 1) / S::U);
 	hipLaunchKernelGGL(fn, dim3(groups), dim3(kWaves * 64), lds, stream, args);
-	return hipGetLastError();
-}
-
-hipError_t launch_dpp_selftest(int* d_out, hipStream_t stream)
-{
-	hipLaunchKernelGGL(v2::dpp_selftest_kernel, dim3(1), dim3(64), 0, stream, d_out);
 	return hipGetLastError();
 }
 
@@ -151,9 +144,6 @@ int synth_rows(int precision, size_t batch, int requested, int section_delay)
 	if (rows != 1 && rows != 2 && rows != 4 && rows != 8) {
 		rows = batch > 512 ? 4 : (batch > 256 ? 2 : 1);
 		// (fp64 used to stop at two rows: with the compact records four fit with a chunk of 32 and run faster)
-#ifdef GVTM_TUNE_F64_ROWS2
-		if (precision == GVTM_PRECISION_F64 && rows > 2) rows = 2;
-#endif
 		// mixed with SectionDelay 3 or 4 (deeper fp64 delay lines per lane): measured 3.36 vs 2.63 and 2.07 vs 1.65 G samples/s
 		if (precision != GVTM_PRECISION_F32 && section_delay >= 3 && rows > 2) rows = 2;
 	}
@@ -270,30 +260,6 @@ hipError_t launch_synth5(const SynthArgs& args, size_t batch, hipStream_t stream
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(batch)), dim3((4 + kM5Helpers) * 64), lds, stream, args);
-	return hipGetLastError();
-}
-
-// Test hook: the all-float path's per-step conversions evaluated ON THE DEVICE
-// (kind 0 = Util::frequency, 1 = Util::amplitude60dB, 2 = tanf stand-in, 3 = cosf stand-in)
-__global__ void float_math_probe_kernel(int kind, const float* x, size_t n, float* out)
-{
-	const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const float v = x[i];
-	float r = 0.0f;
-	switch (kind) {
-	case 0: r = frequency_dev(v); break;
-	case 1: r = amplitude_60db_dev(v); break;
-	case 2: r = tan_dev(v); break;
-	case 3: r = cos_dev(v); break;
-	case 4: r = fdiv_n(v, x[i ^ 1]); break; // (n even)
-	}
-	out[i] = r;
-}
-
-hipError_t launch_float_math_probe(int kind, const float* d_x, size_t n, float* d_out, hipStream_t stream)
-{
-	hipLaunchKernelGGL(float_math_probe_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, kind, d_x, n, d_out);
 	return hipGetLastError();
 }
 

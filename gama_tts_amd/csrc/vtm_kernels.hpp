@@ -57,8 +57,6 @@ struct SynthArgs {
 	union FirByValue { double d[49]; float f[64]; } fir_k;
 	const void* src_h;           // [3328]
 	const void* src_dh;          // [3328]
-	const void* src_coef = nullptr;  // [7][period][4] polyphase coefficients of an up-sampling plan (double precisions), or null
-	unsigned src_period_mask = 0;    // period - 1 (the period is a power of two)
 	const void* noise_lp = nullptr;  // [noise_len] the noise source's low-passed samples by internal step (one-shot launches), or
 	                                 // null: the scan wavefront generates them (streams, whose step count has no bound)
 	unsigned long long noise_len = 0;

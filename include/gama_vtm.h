@@ -46,6 +46,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the libraries are built with -fvisibility=hidden: these entry points are their exports */
+#endif
 
 #define GVTM_N_PARAM 16 /* pitch, glotVol, aspVol, fricVol, fricPos, fricCF, fricBW, r1..r8, velum
                            (vtm/VocalTractModel0.h:160-178) */
@@ -340,6 +343,9 @@ int gvtm_generate_tracks_host(int device, const gvtm_track_config* config, const
 		const int64_t* event_offsets, size_t batch, size_t max_frames, float* params, int32_t* frame_counts,
 		gvtm_drift_state* drift);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -46,10 +46,16 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the libraries are built with -fvisibility=hidden: these entry points are their exports */
+#endif
 
 void* GAMA_TTS_construct_vocal_tract_model(const void* config_data, int is_interactive);
 void GAMA_TTS_destruct_vocal_tract_model(void* vtm);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
