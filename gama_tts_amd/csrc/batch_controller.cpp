@@ -233,7 +233,9 @@ void BatchController::synthesize()
 	for (std::size_t b = 0; b < batch; ++b) {
 		std::copy(utterances_[b].begin(), utterances_[b].end(), params.begin() + static_cast<std::ptrdiff_t>(b * max_frames * GVTM_N_PARAM));
 	}
-	stride_ = gvtm_output_count(plans_.front(), max_frames);
+	// row stride of a ragged batch: on a down-sampling plan a SHORTER utterance that runs into the converter's flush overrun
+	// yields more samples than the longest one (include/gama_vtm.h, gvtm_output_capacity)
+	stride_ = gvtm_output_capacity(plans_.front(), max_frames);
 	if (stride_ == static_cast<std::size_t>(-1)) throw std::runtime_error(gvtm_last_error());
 	audio_.assign(batch * stride_, 0.0f);
 	counts_.assign(batch, 0);
@@ -265,7 +267,11 @@ void BatchController::synthesize()
 }
 
 const float* BatchController::samples(std::size_t i) const { return audio_.data() + i * stride_; }
-std::size_t BatchController::sampleCount(std::size_t i) const { return static_cast<std::size_t>(counts_.at(i)); }
+std::size_t BatchController::sampleCount(std::size_t i) const
+{
+	// (the device clips its writes at the row stride; a count beyond it would be a sizing error above, never a read past the row)
+	return std::min(static_cast<std::size_t>(counts_.at(i)), stride_);
+}
 
 float BatchController::outputScale(std::size_t i) const
 {

@@ -621,7 +621,10 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 		if (steps > kNoiseTableMaxSteps) {
 			// (args.noise_lp stays null)
 		} else if (steps > plan->noise_len) {
-			const size_t want = ((steps + (size_t(1) << 18) - 1) >> 18) << 18;
+			// geometric growth (at least twice the old table, in units of 2^18 steps): a caller whose lengths creep up
+			// retires at most eight tables on the way to the cap
+			size_t want = ((steps + (size_t(1) << 18) - 1) >> 18) << 18;
+			want = std::min(std::max(want, 2 * plan->noise_len), kNoiseTableMaxSteps);
 			const bool f32 = true; // (the double paths generate the samples in the kernel: measured faster there)
 			std::vector<unsigned char> host(want * (f32 ? sizeof(float) : sizeof(double)));
 			gvtm::design_noise_table(want, f32, host.data());
@@ -842,7 +845,7 @@ uint64_t outputs_before(const gvtm::DeviceConstants& k, uint64_t steps)
 
 // One launch on behalf of the stream: utterance b synthesizes n_frames[b] frames from the front of held[b].
 int stream_launch(gvtm_stream* s, const std::vector<size_t>& n_frames, bool final, float* audio, size_t audio_stride, int64_t* out_counts,
-		float* maxabs)
+		float* maxabs, bool* launched = nullptr)
 {
 	gvtm_plan* plan = s->plan;
 	const gvtm::DeviceConstants& k = plan->design.k;
@@ -902,6 +905,7 @@ int stream_launch(gvtm_stream* s, const std::vector<size_t>& n_frames, bool fina
 	const int rc = launch_batch(plan, static_cast<const float*>(s->d_params.ptr), static_cast<const int32_t*>(s->d_frames.ptr), batch, rows_max,
 			static_cast<float*>(s->d_audio.ptr), audio_stride, static_cast<int64_t*>(s->d_counts.ptr), static_cast<float*>(s->d_maxabs.ptr), nullptr, &sl);
 	if (rc != GVTM_OK) return rc;
+	if (launched) *launched = true;
 	if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
 	std::vector<int64_t> got(batch, 0);
 	if ((e = hipMemcpy(got.data(), s->d_counts.ptr, sizeof(int64_t) * batch, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H counts");
@@ -996,6 +1000,15 @@ int gvtm_stream_push(gvtm_stream* s, const float* params, const int32_t* frame_c
 			if (frame_counts[b] < 0 || static_cast<size_t>(frame_counts[b]) > max_frames) return fail(GVTM_ERR_INVALID_ARGUMENT, "frame_counts entry outside [0, max_frames]");
 		}
 	}
+	// a call that fails (a stride too small, a null buffer, an allocation) leaves the stream as it found it: the frames it
+	// appended are taken back, so that the corrected call does not synthesize them twice
+	std::vector<size_t> held_before(s->batch, 0);
+	for (size_t b = 0; b < s->batch; ++b) held_before[b] = s->held[b].size();
+	auto roll_back = [&]() {
+		for (size_t b = 0; b < s->batch; ++b) {
+			if (s->held[b].size() > held_before[b]) s->held[b].resize(held_before[b]);
+		}
+	};
 	try {
 		std::vector<size_t> n(s->batch, 0);
 		for (size_t b = 0; b < s->batch; ++b) {
@@ -1006,8 +1019,12 @@ int gvtm_stream_push(gvtm_stream* s, const float* params, const int32_t* frame_c
 			// the last frame held is the look-ahead of the one before it (Controller.cpp:297-300 interpolates towards the NEXT frame)
 			n[b] = have > 0 ? ((have - 1) / s->granule_frames) * s->granule_frames : 0;
 		}
-		return stream_launch(s, n, false, audio, audio_stride, out_counts, nullptr);
+		bool launched = false;
+		const int rc = stream_launch(s, n, false, audio, audio_stride, out_counts, nullptr, &launched);
+		if (rc != GVTM_OK && !launched) roll_back(); // (after the launch the device state has moved on: gvtm_stream_reset is the way out)
+		return rc;
 	} catch (const std::bad_alloc&) {
+		roll_back();
 		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
 	}
 }

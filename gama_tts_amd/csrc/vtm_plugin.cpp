@@ -276,17 +276,20 @@ private:
 	void finishStream()
 	{
 		if (!steps_.empty()) pushBlock();
-		if (failed_) { output_.clear(); return; }
-		const std::size_t cap = gvtm_stream_capacity(stream_, 0);
-		if (burst_.size() < cap) burst_.resize(cap);
-		int64_t n = 0;
-		if (gvtm_stream_finish(stream_, burst_.data(), burst_.size(), &n, nullptr) != GVTM_OK) {
-			std::fprintf(stderr, "[gama_vtm_plugin] synthesis failed: %s\n", gvtm_last_error());
-			output_.clear();
-			return;
+		if (!failed_) {
+			const std::size_t cap = gvtm_stream_capacity(stream_, 0);
+			if (burst_.size() < cap) burst_.resize(cap);
+			int64_t n = 0;
+			if (gvtm_stream_finish(stream_, burst_.data(), burst_.size(), &n, nullptr) != GVTM_OK) {
+				std::fprintf(stderr, "[gama_vtm_plugin] synthesis failed: %s\n", gvtm_last_error());
+				failed_ = true;
+			} else {
+				output_.insert(output_.end(), burst_.begin(), burst_.begin() + n);
+			}
 		}
-		output_.insert(output_.end(), burst_.begin(), burst_.begin() + n);
-		// the stream is finished: the next utterance needs a fresh one whether or not the host calls reset()
+		if (failed_) output_.clear();
+		// Every finishSynthesis(), failed or not, leaves a clean start: the host only calls reset() when outputBuffer() is
+		// non-empty (Controller.cpp:231), so a failed utterance must not leave its held frames and device state behind.
 		if (gvtm_stream_reset(stream_) != GVTM_OK) failed_ = true;
 	}
 

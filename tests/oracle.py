@@ -338,3 +338,31 @@ def ref_synthesize(params, model="0", output_rate=44100, control_rate=250, confi
             raise RuntimeError("ref_vtm failed: " + r.stderr)
         info = dict(kv.split("=") for kv in r.stdout.split())
         return np.fromfile(pout, dtype=np.float32), info
+
+
+# ---- many oracle references at once ------------------------------------------------------------------------------
+# The C restatement keeps no global state and ctypes releases the GIL for the duration of a call, so a THREAD pool gives
+# one core per utterance without any child process: nothing is forked from (or inherited by) a test process that has
+# already initialised HIP.
+
+def _job_male(job):
+    track, rate, delay, layout, float_model = job
+    return synthesize(male_config(rate, delay, layout, float_model=float_model), track)
+
+
+def _job_male5(job):
+    track, rate = job
+    return synthesize5(male5_config(rate), track)[0]
+
+
+def synthesize_many(jobs, workers=8, model5=False):
+    """jobs: [(track[F][16], rate, delay, layout, float_model)] (model5: [(track, rate)]) -> list of oracle outputs."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    jobs = list(jobs)
+    fn = _job_male5 if model5 else _job_male
+    lib()  # (loaded once, before the threads start)
+    if workers <= 1 or len(jobs) < 2:
+        return [fn(j) for j in jobs]
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, jobs))

@@ -1,8 +1,6 @@
 """Ragged random batches through every model / precision against the oracle: shared by tests/test_gpu_soak.py (reduced,
 -m gpu) and tests/tools/soak.py (large, builder-run).  Float paths must be bit-identical; fp64 paths within one float32
 ulp of the sample or 1e-9 of peak; mixed within 1e-5 of peak (north_star's bar; measured ~3e-7); model 5 within 2e-6 of peak (tests/test_gpu_model5.py explains why)."""
-from concurrent.futures import ProcessPoolExecutor
-
 import numpy as np
 
 import gama_tts_amd as g
@@ -21,19 +19,6 @@ CASES = [  # name, delay, layout, precision, float_model, rate
     ("model4_double_22k", 1, 1, capi.PRECISION_F64, 0, 22050.0),
     ("model0_mixed", 1, 0, capi.PRECISION_MIXED, 0, 44100.0),
 ]
-
-_PARAMS = None
-
-
-def _ref_case(args):
-    b, f, delay, layout, fm, rate = args
-    return oracle.synthesize(oracle.male_config(rate, delay, layout, float_model=fm), _PARAMS[b, :f])
-
-
-def _ref5(args):
-    b, f = args
-    return oracle.synthesize5(oracle.male5_config(48000.0), _PARAMS[b, :f])[0]
-
 
 def make_inputs(batch, max_frames, seed=20261004):
     rng = np.random.default_rng(seed)
@@ -79,33 +64,31 @@ def summarize(audio, counts, refs, exact_required, tol):
 
 
 def run(batch, max_frames, workers=8, names=None, log=None):
-    """-> {case name: summary}.  One launch per case; the references come from the oracle in worker processes."""
-    global _PARAMS
+    """-> {case name: summary}.  One launch per case; the references come from the oracle in spawned worker processes
+    (oracle.synthesize_many: every job carries its own track, nothing is inherited from this process)."""
     params, frames = make_inputs(batch, max_frames)
-    _PARAMS = params
     out = {}
     cfgd = g.read_config_file(oracle.VOICE_MALE)
-    with ProcessPoolExecutor(workers) as ex:  # forked: the workers see _PARAMS
-        for name, delay, layout, prec, fm, rate in CASES:
-            if names is not None and name not in names:
-                continue
-            plan = g.Plan(g.config_from_dict(cfgd, rate, delay, prec, layout), 250.0, 0)
-            fr, n_over = with_overruns(plan, frames, max_frames)
-            audio, counts, _ = plan.synthesize_host(params, fr)
-            refs = list(ex.map(_ref_case, [(b, int(fr[b]), delay, layout, fm, rate) for b in range(batch)], chunksize=16))
-            out[name] = summarize(audio, counts, refs, exact_required=bool(fm), tol=1e-5 if prec == capi.PRECISION_MIXED else 2e-7)
-            out[name]["flush_overrun_utterances"] = n_over
-            out[name]["frame_counts_lowered"] = 0
-            if log:
-                log(name, out[name])
-        if names is None or "model5_double" in names:
-            plan = g.Plan(g.config5_from_dict(g.read_config_file(oracle.VOICE5_MALE)), 250.0, 0)
-            fr, n_over = with_overruns(plan, frames, max_frames)
-            audio, counts, _ = plan.synthesize_host(params, fr)
-            refs = list(ex.map(_ref5, [(b, int(fr[b])) for b in range(batch)], chunksize=16))
-            out["model5_double"] = summarize(audio, counts, refs, exact_required=False, tol=2e-6)
-            out["model5_double"]["flush_overrun_utterances"] = n_over
-            out["model5_double"]["frame_counts_lowered"] = 0
-            if log:
-                log("model5_double", out["model5_double"])
+    for name, delay, layout, prec, fm, rate in CASES:
+        if names is not None and name not in names:
+            continue
+        plan = g.Plan(g.config_from_dict(cfgd, rate, delay, prec, layout), 250.0, 0)
+        fr, n_over = with_overruns(plan, frames, max_frames)
+        audio, counts, _ = plan.synthesize_host(params, fr)
+        refs = oracle.synthesize_many([(params[b, : int(fr[b])], rate, delay, layout, fm) for b in range(batch)], workers)
+        out[name] = summarize(audio, counts, refs, exact_required=bool(fm), tol=1e-5 if prec == capi.PRECISION_MIXED else 2e-7)
+        out[name]["flush_overrun_utterances"] = n_over
+        out[name]["frame_counts_lowered"] = 0
+        if log:
+            log(name, out[name])
+    if names is None or "model5_double" in names:
+        plan = g.Plan(g.config5_from_dict(g.read_config_file(oracle.VOICE5_MALE)), 250.0, 0)
+        fr, n_over = with_overruns(plan, frames, max_frames)
+        audio, counts, _ = plan.synthesize_host(params, fr)
+        refs = oracle.synthesize_many([(params[b, : int(fr[b])], 48000.0) for b in range(batch)], workers, model5=True)
+        out["model5_double"] = summarize(audio, counts, refs, exact_required=False, tol=2e-6)
+        out["model5_double"]["flush_overrun_utterances"] = n_over
+        out["model5_double"]["frame_counts_lowered"] = 0
+        if log:
+            log("model5_double", out["model5_double"])
     return out

@@ -276,6 +276,33 @@ def test_header_is_plain_c_and_the_c_example_builds(tmp_path):
         assert "utterance 1: 88108 samples" in r.stdout
 
 
+def test_ragged_example_sizes_rows_with_output_capacity(tmp_path):
+    """examples/synthesize_ragged.c = the INTEGRATION.md snippet compiled: a ragged batch on a down-sampling plan (reference
+    model 3 at 44.1 kHz) whose 2334-frame utterance hits the converter's flush overrun and is LONGER than its 2335-frame
+    neighbour; the row stride must be gvtm_output_capacity(plan, max_frames).  Design-only without a device (it stops at the
+    synthesis call), the whole batch with one; both lengths are pinned by the reference-made vectors of
+    tests/golden/vtm_overrun_golden.npz (tests/test_gpu_overrun.py)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(g.library_path())
+    exe = str(tmp_path / "synthesize_ragged")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + inc, os.path.join(ROOT, "examples", "synthesize_ragged.c"),
+                    "-L" + libdir, "-lgama_vtm", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "utterance 0: 2334 frames -> 411798 samples" in r.stdout
+    assert "utterance 1: 2335 frames -> 411223 samples" in r.stdout
+    # (the capacity is the maximum over EVERY length up to max_frames: another overrun length below 2334 yields 411974)
+    assert "gvtm_output_count(max_frames) = 411223, gvtm_output_capacity(max_frames) = 411974" in r.stdout
+    if g.device_count() == 0:
+        assert "no HIP device" in r.stdout
+    else:
+        assert "utterance 0: 411798 samples in a row of 411974" in r.stdout
+
+
 def test_noise_table_is_the_reference_sequence():
     """The per-plan table of noise samples (csrc/vtm_design.cpp: design_noise_table) against a numpy restatement of
     NoiseSource::getSample + NoiseFilter::filter (vtm/NoiseSource.h:40-44, vtm/NoiseFilter.h:63-68): seed 0.7892347,
