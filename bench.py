@@ -20,12 +20,21 @@ gama_tts_amd.shard.shard_range, every rank synthesizes its own shard (independen
 no data-path collective — SURVEY.md 8e); the only communication is the barrier and the MAX of
 the elapsed time.
 
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its N ranks itself: before anything touches a GPU
+the parent spawns one fresh child process per device (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
+127.0.0.1 rendezvous), relays rank 0's line and exits with the worst child status -- the torch.distributed.run path is
+unchanged.
+
 Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes per launch (64 B per
 input frame + 4 B per output sample) / the synthesis kernel's mean duration
 measured with HIP events on the launch stream; `roofline.valu` prices the same launches against
 the vector-ALU peak (the resource that actually binds).  `cpu_baseline` times the
 real reference (oracle/_ref, compiled from /root/reference in the build container; "port" = our
-C oracle when that binary is absent) on one host core over a bounded sample of the same workload.
+C oracle when that binary is absent) on one host core over a bounded sample of the same workload, once per reference class
+(float and double), with the host CPU's model and core count beside it.  `parity_check` compares two utterances of the
+TIMED output buffer with the oracle after the timed region (the oracle is the checker here, never the thing measured);
+`end_to_end` times the host-buffer entries (H2D frames + kernel + D2H samples through page-locked buffers, float32 and
+int16 output) beside the kernel-only `value`, never instead of it.
 """
 import argparse
 import json
@@ -88,6 +97,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the extra single-GPU measurements (other precisions and sizes)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-buffer (H2D + kernel + D2H) measurements")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle comparison of the timed output")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU work at all: the ranks only rendezvous (gloo), cut the batch into their shards and rank 0 prints "
+                         "them -- a CPU rehearsal of the launcher and the rank logic, not a measurement")
     args = ap.parse_args(argv)
     if args.model in (4, 5):
         # the other tubes keep round 1's 256 x 2 s workload (one utterance per workgroup at that size)
@@ -124,12 +138,27 @@ def reference_class(precision, delay, model):
     return cls, how
 
 
-def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, model5=False, model4=False):
+def host_identity():
+    """(CPU model name, logical cores) of this host from /proc/cpuinfo."""
+    model, cores = None, 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model is None:
+                    model = line.split(":", 1)[1].strip()
+                if line.startswith("processor"):
+                    cores += 1
+    except OSError:
+        pass
+    return model, (cores or os.cpu_count() or 0)
+
+
+def cpu_baseline(params, output_rate, delay, budget_s=6.0, float_model=False, model5=False, model4=False):
     """Single-thread CPU throughput (output samples/s) on a bounded sample of the workload."""
     import oracle
     voice = oracle.VOICE5_MALE if model5 else oracle.VOICE_MALE
 
-    sample = params[:4]
+    sample = params[:2]
     kind = None
     exe_kind = None
     flags = ""
@@ -181,7 +210,156 @@ def cpu_baseline(params, output_rate, delay, budget_s=12.0, float_model=False, m
                 total_samples += synth(tr).size
         total_sec = time.perf_counter() - t0
         desc = "%d utterances x %d repeats of %d frames through oracle/vtm_oracle.c" % (len(sample), repeat, sample.shape[1])
-    return {"value": total_samples / total_sec, "unit": "samples/s", "cores": 1, "kind": kind, "sample": desc}
+    cpu_model, host_cores = host_identity()
+    return {"value": total_samples / total_sec, "unit": "samples/s", "cores": 1, "kind": kind, "sample": desc,
+            "reference_class": reference_class("f32" if float_model else "f64", delay, 5 if model5 else (4 if model4 else 0))[0],
+            "cpu_model": cpu_model, "host_cores": host_cores}
+
+
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_plan(n_ranks, argv, port):
+    """The N child processes `bench.py --gpus N` starts when no launcher has: [(command, environment additions)], one per
+    device, rendezvous on 127.0.0.1 (what torch.distributed.run would have exported)."""
+    plan = []
+    for r in range(n_ranks):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+        plan.append(([sys.executable, os.path.abspath(__file__)] + list(argv), env))
+    return plan
+
+
+def self_launch(args, argv, timeout_s=1500.0):
+    """Start the ranks as fresh child processes (this process has not touched a GPU and never will), relay rank 0's
+    output, return the worst exit status.  A rank that fails takes the others down with it (they would wait in the
+    barrier forever)."""
+    import subprocess
+
+    procs = []
+    for r, (cmd, env_add) in enumerate(launch_plan(args.gpus, argv, free_port())):
+        env = dict(os.environ)
+        env.update(env_add)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + timeout_s
+    status = [None] * len(procs)
+    while any(st is None for st in status):
+        for i, pr in enumerate(procs):
+            if status[i] is None:
+                status[i] = pr.poll()
+        failed = any(st not in (None, 0) for st in status)
+        if failed or time.time() > deadline:
+            for i, pr in enumerate(procs):
+                if status[i] is None:
+                    pr.terminate()  # (our own children, by handle)
+            for i, pr in enumerate(procs):
+                if status[i] is None:
+                    try:
+                        status[i] = pr.wait(timeout=20)
+                    except Exception:
+                        pr.kill()
+                        status[i] = pr.wait()
+            if not failed:
+                print("bench.py: ranks still running after %.0f s, stopped" % timeout_s, file=sys.stderr)
+                return 124
+            break
+        time.sleep(0.05)
+    return max(abs(int(st or 0)) for st in status)
+
+
+def rehearse_launch(args):
+    """--rehearse-launch: everything `--gpus N` does around the GPU work and nothing of it: rendezvous (gloo), shard
+    computation, barrier, MAX over ranks; rank 0 prints the shards.  Runs on a CPU-only box (tests/test_shard_gloo.py)."""
+    import torch.distributed as dist
+    from gama_tts_amd.shard import max_over_ranks
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    total, lo, hi = rank_workload(args, rank, world)
+    spans = [None] * world
+    if world > 1:
+        dist.all_gather_object(spans, (lo, hi))
+        dist.barrier()
+        slowest = max_over_ranks(1.0 + rank, dist)
+    else:
+        spans = [(lo, hi)]
+        slowest = 1.0
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "global_batch": total, "shards": [list(x) for x in spans],
+                          "max_over_ranks_of_1_plus_rank": slowest, "launcher": "self" if os.environ.get("GVTM_BENCH_SELF_LAUNCHED") else "external"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+PARITY_TOL = {"f32": 0.0, "mixed": 1e-5, "f64": 1e-9}
+PARITY_TOL_LONG_F64 = 5e-8  # 30 s in double: the device's and glibc's exp2 / pow differ in the last bit (tests/test_gpu_parity.py)
+
+
+def parity_check(d_audio, host_tracks, rows, precision, delay, frames, output_rate, model=0):
+    """Utterances `rows` of the TIMED output buffer against the oracle (peak-relative error; float: bit for bit)."""
+    import numpy as np
+    import oracle
+
+    worst, same = 0.0, True
+    for b in rows:
+        got = d_audio[b].cpu().numpy()
+        tr = host_tracks[b % len(host_tracks)][:frames]
+        if model == 5:
+            ref = oracle.synthesize5(oracle.male5_config(output_rate), tr)[0]
+        else:
+            ref = oracle.synthesize(oracle.male_config(output_rate, delay, 1 if model == 4 else 0, float_model=int(precision == "f32")), tr)
+        if ref.size != got.size:
+            return {"utterances": list(rows), "pass": False, "error": "sample count %d != oracle %d" % (got.size, ref.size)}
+        same = same and bool(np.array_equal(got, ref))
+        peak = float(np.abs(ref).max())
+        if peak > 0:
+            worst = max(worst, float(np.abs(got.astype(np.float64) - ref).max() / peak))
+    tol = 2e-6 if model == 5 else (PARITY_TOL_LONG_F64 if (precision == "f64" and frames > 2000) else PARITY_TOL[precision])
+    ok = same if precision == "f32" and model != 5 else worst <= max(tol, 6e-8)  # (double paths: a float32 sample may flip by one ulp)
+    return {"utterances": list(rows), "max_err": worst, "bit_identical": same, "tolerance": "bit-identical" if (precision == "f32" and model != 5) else tol,
+            "against": "oracle/vtm_oracle.c (pinned to reference-made vectors), same tracks, after the timed region", "pass": bool(ok)}
+
+
+def end_to_end(g, plan, host_pool, batch, frames, n_timed, kernel_only_rate, label):
+    """The host-buffer entries on page-locked buffers: H2D frames + kernel + D2H samples, float32 and int16 output
+    (include/gama_vtm.h: gvtm_synthesize_batch_host, gvtm_synthesize_batch_host_pcm16)."""
+    import numpy as np
+
+    n_out = plan.output_count(frames)
+    p_in = g.PinnedArray((batch, frames, 16), np.float32)
+    reps = (batch + len(host_pool) - 1) // len(host_pool)
+    for r in range(reps):
+        lo = r * len(host_pool)
+        n = min(len(host_pool), batch - lo)
+        p_in.array[lo:lo + n] = host_pool[:n, :frames]
+    raw = g.PinnedArray((batch * n_out,), np.float32)  # viewed as float32 [B][N] or int16 [B][N] (its first half)
+    counts = np.zeros(batch, np.int64)
+    out = []
+    for kind in ("int16", "float32"):
+        buf = raw.array.view(np.int16)[: batch * n_out].reshape(batch, n_out) if kind == "int16" else raw.array.reshape(batch, n_out)
+        plan.synthesize_host_into(p_in.array, buf, None, counts, None)  # warm-up: staging buffers, streams
+        t0 = time.perf_counter()
+        for _ in range(n_timed):
+            plan.synthesize_host_into(p_in.array, buf, None, counts, None)
+        el = (time.perf_counter() - t0) / n_timed
+        assert int(counts.min()) == n_out and int(counts.max()) == n_out
+        rate = float(n_out) * batch / el
+        out.append({"workload": label, "output": kind, "ms": el * 1e3, "value": rate, "unit": "samples/s",
+                    "bytes_over_pcie": float(batch) * (frames * 64.0 + n_out * (2.0 if kind == "int16" else 4.0)),
+                    "pcie_gbs": float(batch) * (frames * 64.0 + n_out * (2.0 if kind == "int16" else 4.0)) / el / 1e9,
+                    "vs_kernel_only": rate / kernel_only_rate if kernel_only_rate else None,
+                    "host_buffers": "page-locked (gvtm_host_alloc = hipHostMalloc)"})
+    p_in.close()
+    raw.close()
+    return out
 
 
 def traffic_entry(batch, frames, delay, precision, model):
@@ -197,6 +375,12 @@ def traffic_entry(batch, frames, delay, precision, model):
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves, BEFORE anything touches a GPU (this process never does)
+        os.environ["GVTM_BENCH_SELF_LAUNCHED"] = "1"
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if args.rehearse_launch:
+        return rehearse_launch(args)
 
     import numpy as np  # noqa: F401
     import torch
@@ -209,8 +393,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("bench.py --gpus %d: the launcher started %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the VTM path has no CPU fallback")
     if args.single_device:
@@ -281,6 +464,12 @@ def main():
     plan.set_timing(False)
     if batch:
         assert int(d_counts[:batch].min().item()) == n_out and int(d_counts[:batch].max().item()) == n_out
+    parity = None
+    if rank == 0 and batch and not args.no_parity_check:
+        # two utterances of the buffer the timed launches wrote, against the oracle (outside the timed region)
+        parity = parity_check(d_audio, host_pool, sorted({0, min(batch, pool) - 1}), args.precision, args.delay, args.frames, args.output_rate, args.model)
+        if not parity["pass"]:
+            raise SystemExit("bench.py: the timed output does not match the oracle: %s" % json.dumps(parity))
 
     from gama_tts_amd.shard import max_over_ranks
     elapsed = max_over_ranks(elapsed, dist, dev if args.dist_backend == "nccl" else None)
@@ -350,16 +539,40 @@ def main():
                 },
             },
         }
-        if world == 1 and not args.no_extras and not model5 and not model4:
-            line["extras"] = extras(args, g, make_plan, tiled, d_audio, d_counts, stream, n_out)
+        line["parity_check"] = parity
+        plain = not model5 and not model4
+        if world == 1 and not args.no_extras and plain:
+            line["extras"] = extras(args, g, make_plan, tiled, d_audio, d_counts, stream, n_out, host_pool)
+        if world == 1 and not args.no_end_to_end and plain:
+            # kernel-only rates beside which the host-buffer entries are quoted
+            k2s = next((e["value"] for e in line.get("extras", []) if (e["precision"], e["batch"], e["frames"], e["section_delay"]) == (args.precision, 4096, 500, 1)), None)
+            e2e = end_to_end(g, make_plan(args.precision, 1), host_pool, 4096, 500, 3, k2s, "4096 x 500 frames (2 s), SectionDelay 1, %s" % args.precision)
+            if (batch, args.frames) == (DEFAULT_BATCH_PER_GPU, DEFAULT_FRAMES):
+                e2e += end_to_end(g, plan, host_pool, batch, args.frames, 2, value, "BASELINE configs[3]: %d x %d frames, SectionDelay %d, %s" % (batch, args.frames, args.delay, args.precision))
+            line["end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=args.precision == "f32", model5=model5, model4=model4)
+            # one core of this host through the compiled reference, once per reference class (float / double)
+            by_class = {}
+            for cls, fm in (("float", True), ("double", False)):
+                if model5 and fm:
+                    continue
+                by_class[cls] = cpu_baseline(host_pool, args.output_rate, args.delay, float_model=fm, model5=model5, model4=model4)
+            mine = "float" if (args.precision == "f32" and not model5) else "double"
+            line["cpu_baseline"] = by_class[mine]
+            line["cpu_baseline_by_class"] = by_class
+            if plain and "extras" in line:
+                d1 = {"float": cpu_baseline(host_pool[:, :500], args.output_rate, 1, budget_s=3.0, float_model=True),
+                      "double": cpu_baseline(host_pool[:, :500], args.output_rate, 1, budget_s=3.0, float_model=False)}
+                for e in line["extras"]:
+                    ref = (by_class if e["section_delay"] == args.delay else d1)["float" if e["precision"] == "f32" else "double"]
+                    e["cpu_baseline"] = {"value": ref["value"], "unit": "samples/s", "cores": 1, "kind": ref["kind"], "reference_class": ref["reference_class"],
+                                         "gpu_over_one_core": e["value"] / ref["value"]}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def extras(args, g, make_plan, tiled, d_audio, d_counts, stream, n_out_main):
+def extras(args, g, make_plan, tiled, d_audio, d_counts, stream, n_out_main, host_pool):
     """Other precisions and sizes on the same GPU, short runs beside the headline: the fp32 / fp64 sweep of
     configs[3], the batch BASELINE's target is quoted on with 2 s tracks, and configs[1] (256 x 2 s, VTM0).  The
     256 x 2 s entries also say how far each precision's samples are from the fp64 path's (which the tests hold
@@ -387,13 +600,19 @@ def extras(args, g, make_plan, tiled, d_audio, d_counts, stream, n_out_main):
         el = time.perf_counter() - t_e
         kms, _ = pl.take_kernel_ms()
         assert int(dc.min().item()) == n_out
+        par = None
+        if not args.no_parity_check:
+            par = parity_check(da, host_pool, sorted({0, min(batch, len(host_pool)) - 1}), precision, delay, frames, args.output_rate)
+            if not par["pass"]:
+                raise SystemExit("bench.py: the timed output of %s %d x %d does not match the oracle: %s" % (precision, batch, frames, json.dumps(par)))
         cls, _how = reference_class(precision, delay, 0)
         flops = float(batch) * (steps * FLOP_PER_STEP + n_out * FLOP_PER_OUTPUT)
         e = {"precision": precision, "batch": batch, "frames": frames, "section_delay": delay, "reproduces": cls,
              "value": float(n_out) * batch * n_timed / el, "unit": "samples/s", "kernel_ms": kms,
              "real_time_factor": float(n_out) * batch * n_timed / el / args.output_rate,
              "hbm_gbs": float(batch) * (frames * 64.0 + n_out * 4.0) / (kms * 1e-3) / 1e9,
-             "valu_tflops": flops / (kms * 1e-3) / 1e12, "valu_frac": flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS[precision]}
+             "valu_tflops": flops / (kms * 1e-3) / 1e12, "valu_frac": flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS[precision],
+             "parity_check": par}
         if keep is not None:
             keep[precision] = da.clone()
         del dp

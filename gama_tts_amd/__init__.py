@@ -7,6 +7,7 @@ raises when the native library is missing.
 """
 from .capi import (  # noqa: F401
     GvtmError,
+    PinnedArray,
     Plan,
     Stream,
     TrackConfig,

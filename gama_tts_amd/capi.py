@@ -145,6 +145,12 @@ def load_library(diagnostics=False):
     L.gvtm_synthesize_batch_device.restype = i32
     L.gvtm_synthesize_batch_host.argtypes = [vp, vp, vp, sz, sz, vp, sz, vp, vp]
     L.gvtm_synthesize_batch_host.restype = i32
+    L.gvtm_synthesize_batch_host_pcm16.argtypes = [vp, vp, vp, sz, sz, vp, sz, vp, vp, vp]
+    L.gvtm_synthesize_batch_host_pcm16.restype = i32
+    L.gvtm_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
+    L.gvtm_host_alloc.restype = i32
+    L.gvtm_host_free.argtypes = [vp]
+    L.gvtm_host_free.restype = None
     L.gvtm_normalize_batch_device.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.gvtm_normalize_batch_device.restype = i32
     L.gvtm_tracks_frame_count.argtypes = [ctypes.POINTER(TrackConfig), vp, sz]
@@ -183,6 +189,34 @@ def load_library(diagnostics=False):
 
 def device_count():
     return int(load_library().gvtm_device_count())
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory from gvtm_host_alloc (the buffers of the host entries: with them the
+    H2D / kernel / D2H pipeline really overlaps).  Keep the object alive as long as `.array` is in use."""
+
+    def __init__(self, shape, dtype):
+        self._lib = load_library()
+        self.array = None
+        self._ptr = ctypes.c_void_p()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        rc = self._lib.gvtm_host_alloc(max(nbytes, 1), ctypes.byref(self._ptr))
+        if rc != 0:
+            raise GvtmError(rc, self._lib.gvtm_last_error().decode())
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._ptr:
+            self.array = None
+            self._lib.gvtm_host_free(self._ptr)
+            self._ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def read_config_file(path):
@@ -325,6 +359,7 @@ class Plan:
         """diagnostics=True binds the plan to libgama_vtm_diag.so (gvtm_debug_* hooks); rows (diagnostics only) forces
         the utterances per workgroup, i.e. the kernel shape a big batch would get."""
         self._lib = load_library(diagnostics)
+        self.diagnostics = bool(diagnostics)
         self._h = ctypes.c_void_p()
         self.config = config
         create = self._lib.gvtm_plan_create_model5 if isinstance(config, Config5) else self._lib.gvtm_plan_create
@@ -398,6 +433,35 @@ class Plan:
         self._check(self._lib.gvtm_synthesize_batch_host(
             self._h, _ptr(params), _ptr(fc), batch, frames, _ptr(audio), stride, _ptr(counts), _ptr(maxabs)))
         return audio, counts, maxabs
+
+    def synthesize_host_into(self, params, out, frame_counts=None, counts=None, maxabs=None, scales=None):
+        """The host entries with caller-owned (e.g. page-locked) buffers: `out` float32 [B][stride] takes the unscaled
+        samples (gvtm_synthesize_batch_host), `out` int16 [B][stride] the scaled 16-bit ones (.._host_pcm16)."""
+        assert params.dtype == np.float32 and params.flags.c_contiguous and params.ndim == 3 and params.shape[2] == N_PARAM
+        assert out.flags.c_contiguous and out.ndim == 2 and out.shape[0] == params.shape[0]
+        batch, frames = params.shape[:2]
+        fc = None
+        if frame_counts is not None:
+            fc = np.ascontiguousarray(frame_counts, dtype=np.int32)
+        if out.dtype == np.int16:
+            self._check(self._lib.gvtm_synthesize_batch_host_pcm16(
+                self._h, _ptr(params), _ptr(fc), batch, frames, _ptr(out), out.shape[1], _ptr(counts), _ptr(maxabs), _ptr(scales)))
+        else:
+            assert out.dtype == np.float32 and scales is None
+            self._check(self._lib.gvtm_synthesize_batch_host(
+                self._h, _ptr(params), _ptr(fc), batch, frames, _ptr(out), out.shape[1], _ptr(counts), _ptr(maxabs)))
+
+    def synthesize_host_pcm16(self, params, frame_counts=None):
+        """-> (pcm int16 [B][stride], counts int64 [B], maxabs float32 [B], scales float32 [B])"""
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        batch, frames = params.shape[:2]
+        stride = self.output_count(frames) if frame_counts is None else self.output_capacity(frames)
+        pcm = np.zeros((batch, stride), dtype=np.int16)
+        counts = np.zeros(batch, dtype=np.int64)
+        maxabs = np.zeros(batch, dtype=np.float32)
+        scales = np.zeros(batch, dtype=np.float32)
+        self.synthesize_host_into(params, pcm, frame_counts, counts, maxabs, scales)
+        return pcm, counts, maxabs, scales
 
     def normalize_device(self, d_audio, batch, audio_stride, d_maxabs, d_counts=None, d_out_f32=None, d_out_i16=None,
                          d_scales=None, stream=None):

@@ -2,7 +2,9 @@
 
 #include <thread>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
@@ -183,6 +185,9 @@ BatchController::BatchController(const std::map<std::string, std::string>& merge
 
 BatchController::~BatchController()
 {
+	params_buf_.release();
+	audio_buf_.release();
+	pcm_buf_.release();
 	for (gvtm_plan* p : plans_) gvtm_plan_destroy(p);
 }
 
@@ -218,10 +223,37 @@ std::size_t BatchController::addUtterance(std::vector<float> frames)
 	return utterances_.size() - 1;
 }
 
-void BatchController::synthesize()
+void BatchController::HostBuffer::release()
+{
+	if (ptr) {
+		if (pinned) gvtm_host_free(ptr);
+		else std::free(ptr);
+	}
+	ptr = nullptr;
+	bytes = 0;
+	pinned = false;
+}
+
+void BatchController::HostBuffer::resize(std::size_t need)
+{
+	if (need <= bytes) return;
+	release();
+	void* p = nullptr;
+	if (gvtm_host_alloc(need, &p) == GVTM_OK && p) {
+		pinned = true;
+	} else {
+		p = std::malloc(need);
+		if (!p) throw std::bad_alloc();
+	}
+	ptr = p;
+	bytes = need;
+}
+
+void BatchController::synthesize(Output output)
 {
 	const std::size_t batch = utterances_.size();
 	shards_.assign(plans_.size(), {0, 0});
+	output_ = output;
 	if (batch == 0) return;
 	std::size_t max_frames = 0;
 	std::vector<int32_t> frames(batch);
@@ -229,15 +261,23 @@ void BatchController::synthesize()
 		frames[b] = static_cast<int32_t>(utterances_[b].size() / GVTM_N_PARAM);
 		max_frames = std::max<std::size_t>(max_frames, static_cast<std::size_t>(frames[b]));
 	}
-	std::vector<float> params(batch * max_frames * GVTM_N_PARAM, 0.0f);
+	const std::size_t row_in = max_frames * GVTM_N_PARAM;
+	params_buf_.resize(sizeof(float) * std::max<std::size_t>(batch * row_in, 1));
+	float* const params = static_cast<float*>(params_buf_.ptr);
 	for (std::size_t b = 0; b < batch; ++b) {
-		std::copy(utterances_[b].begin(), utterances_[b].end(), params.begin() + static_cast<std::ptrdiff_t>(b * max_frames * GVTM_N_PARAM));
+		float* row = params + b * row_in;
+		std::copy(utterances_[b].begin(), utterances_[b].end(), row);
+		std::fill(row + utterances_[b].size(), row + row_in, 0.0f);
 	}
 	// row stride of a ragged batch: on a down-sampling plan a SHORTER utterance that runs into the converter's flush overrun
 	// yields more samples than the longest one (include/gama_vtm.h, gvtm_output_capacity)
 	stride_ = gvtm_output_capacity(plans_.front(), max_frames);
 	if (stride_ == static_cast<std::size_t>(-1)) throw std::runtime_error(gvtm_last_error());
-	audio_.assign(batch * stride_, 0.0f);
+	const bool pcm16 = output == Output::Pcm16;
+	if (pcm16) pcm_buf_.resize(sizeof(int16_t) * std::max<std::size_t>(batch * stride_, 1));
+	else audio_buf_.resize(sizeof(float) * std::max<std::size_t>(batch * stride_, 1));
+	float* const audio = static_cast<float*>(audio_buf_.ptr);
+	int16_t* const pcm = static_cast<int16_t*>(pcm_buf_.ptr);
 	counts_.assign(batch, 0);
 	maxabs_.assign(batch, 0.0f);
 	// contiguous shards whose sizes differ by at most one; every shard on its own host thread and device
@@ -250,9 +290,12 @@ void BatchController::synthesize()
 		const std::size_t hi = lo + base + (d < extra ? 1 : 0);
 		shards_[d] = {lo, hi};
 		if (hi > lo) {
-			auto run = [this, d, lo, hi, max_frames, &params, &frames, &errors]() {
-				const int rc = gvtm_synthesize_batch_host(plans_[d], params.data() + lo * max_frames * GVTM_N_PARAM, frames.data() + lo,
-						hi - lo, max_frames, audio_.data() + lo * stride_, stride_, counts_.data() + lo, maxabs_.data() + lo);
+			auto run = [this, d, lo, hi, max_frames, row_in, params, audio, pcm, pcm16, &frames, &errors]() {
+				const int rc = pcm16
+					? gvtm_synthesize_batch_host_pcm16(plans_[d], params + lo * row_in, frames.data() + lo, hi - lo, max_frames,
+							pcm + lo * stride_, stride_, counts_.data() + lo, maxabs_.data() + lo, nullptr)
+					: gvtm_synthesize_batch_host(plans_[d], params + lo * row_in, frames.data() + lo, hi - lo, max_frames,
+							audio + lo * stride_, stride_, counts_.data() + lo, maxabs_.data() + lo);
 				if (rc != GVTM_OK) errors[d] = gvtm_last_error(); // thread-local message
 			};
 			if (n_dev == 1) run();
@@ -266,7 +309,18 @@ void BatchController::synthesize()
 	}
 }
 
-const float* BatchController::samples(std::size_t i) const { return audio_.data() + i * stride_; }
+const float* BatchController::samples(std::size_t i) const
+{
+	if (output_ != Output::Float32 || !audio_buf_.ptr) throw std::logic_error("samples(): the last synthesize() did not bring float samples back");
+	return static_cast<const float*>(audio_buf_.ptr) + i * stride_;
+}
+
+const int16_t* BatchController::pcm(std::size_t i) const
+{
+	if (output_ != Output::Pcm16 || !pcm_buf_.ptr) throw std::logic_error("pcm(): the last synthesize() did not bring 16-bit samples back");
+	return static_cast<const int16_t*>(pcm_buf_.ptr) + i * stride_;
+}
+
 std::size_t BatchController::sampleCount(std::size_t i) const
 {
 	// (the device clips its writes at the row stride; a count beyond it would be a sizing error above, never a read past the row)
@@ -303,9 +357,15 @@ void BatchController::writeWav(std::size_t i, const std::string& path) const
 	std::fputs("fmt ", f); u32(16); u16(1); u16(1);
 	u32(static_cast<int>(std::round(rate))); u32(static_cast<int>(std::ceil(rate * 2))); u16(2); u16(16);
 	std::fputs("data", f); u32(data_bytes);
-	const float scale = outputScale(i);
-	const float* x = samples(i);
-	for (int s = 0; s < n; ++s) u16(static_cast<int>(std::round((x[s] * scale) * 32767.0f))); // writeSample, WAVEFileWriter.cpp:122-125
+	if (output_ == Output::Pcm16) {
+		// scaled and rounded on the device by the same rule (vtm_normalize_kernel)
+		const int16_t* x = pcm(i);
+		for (int s = 0; s < n; ++s) u16(static_cast<int>(x[s]));
+	} else {
+		const float scale = outputScale(i);
+		const float* x = samples(i);
+		for (int s = 0; s < n; ++s) u16(static_cast<int>(std::round((x[s] * scale) * 32767.0f))); // writeSample, WAVEFileWriter.cpp:122-125
+	}
 	std::fclose(f);
 }
 

@@ -49,16 +49,24 @@ public:
 	std::size_t addUtterance(std::vector<float> frames /* [n][16] */);
 	std::size_t size() const { return utterances_.size(); }
 
-	// Controller::synthesize + finishSynthesis for every queued utterance (one launch per device).
-	void synthesize();
+	// What synthesize() brings back from the device:
+	//   Float32  the unscaled outputBuffer() samples (samples(), scaledBuffer(), writeWav() all work)
+	//   Pcm16    the int16 samples Controller::writeOutputToFile would put into the WAV file, scaled and rounded on the
+	//            device (half the bytes over PCIe; pcm() and writeWav() work) -- what the batched CLI uses
+	enum class Output { Float32, Pcm16 };
+	// Controller::synthesize + finishSynthesis for every queued utterance (one launch per device, or a pipeline of slices
+	// for big batches: include/gama_vtm.h, gvtm_synthesize_batch_host*).  Host buffers are page-locked.
+	void synthesize(Output output = Output::Float32);
 	std::size_t deviceCount() const { return plans_.size(); }
 	// [first, last) utterance indices handed to device slot `d` by the last synthesize()
 	std::pair<std::size_t, std::size_t> shard(std::size_t d) const { return shards_.at(d); }
 
 	double outputSampleRate() const { return config_.output_rate; }
 	double internalSampleRate() const;
-	// Unscaled samples of utterance i (VocalTractModel::outputBuffer()).
+	// Unscaled samples of utterance i (VocalTractModel::outputBuffer()); Output::Float32 only.
 	const float* samples(std::size_t i) const;
+	// The utterance's 16-bit samples as the WAV file holds them; Output::Pcm16 only.
+	const int16_t* pcm(std::size_t i) const;
 	std::size_t sampleCount(std::size_t i) const;
 	// Util::calculateOutputScale: 0.95 / max|x|, 0 below 1e-30 (VTMUtil.cpp:48-67).
 	float outputScale(std::size_t i) const;
@@ -73,7 +81,16 @@ private:
 	std::vector<gvtm_plan*> plans_; // one per device slot
 	std::vector<std::pair<std::size_t, std::size_t>> shards_;
 	std::vector<std::vector<float>> utterances_;
-	std::vector<float> audio_;
+	// page-locked host buffers (gvtm_host_alloc; plain memory when that fails), freed by the destructor
+	struct HostBuffer {
+		void* ptr = nullptr;
+		std::size_t bytes = 0;
+		bool pinned = false;
+		void resize(std::size_t need);
+		void release();
+	};
+	HostBuffer params_buf_, audio_buf_, pcm_buf_;
+	Output output_ = Output::Float32;
 	std::vector<int64_t> counts_;
 	std::vector<float> maxabs_;
 	std::size_t stride_ = 0;

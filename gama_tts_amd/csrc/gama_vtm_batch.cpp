@@ -70,7 +70,7 @@ int main(int argc, char** argv)
 			if (!in) { std::cerr << "Could not open the file " << argv[a] << '.' << std::endl; return EXIT_FAILURE; }
 			controller.addUtteranceFromStream(in);
 		}
-		controller.synthesize();
+		controller.synthesize(gvtm::BatchController::Output::Pcm16); // the WAV files' own 16-bit samples come back from the device
 		for (std::size_t u = 0; u < controller.size(); ++u) {
 			const std::string path = out_dir + "/" + names[u] + ".wav";
 			controller.writeWav(u, path);

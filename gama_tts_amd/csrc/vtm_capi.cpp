@@ -103,16 +103,18 @@ struct gvtm_plan {
 	gvtm::DeviceConstants* d_consts = nullptr;
 	gvtm::Model5Constants* d_consts5 = nullptr; // model 5 plans only
 	// staging for the host-buffer entry point
-	DeviceBuffer s_params, s_frames, s_audio, s_counts, s_maxabs;
+	DeviceBuffer s_params, s_frames, s_audio, s_counts, s_maxabs, s_pcm, s_scales;
+	int compute_units = 0; // of the plan's device (the host entries cut big batches into slices that fill them once)
 	// kernel timing (HIP events on the launch stream)
 	bool timing = false;
 	double* debug_taps = nullptr; // device pointer (diagnostics builds: gvtm_debug_set_taps)
 	unsigned long long* phase_cycles = nullptr; // device pointer (diagnostics builds: gvtm_debug_set_phase_cycles)
 	std::vector<EventPair> pending;
 	std::vector<EventPair> pool;
-	// host-buffer entry on large batches: kernels on one stream, copies back on another (created on first use)
-	hipStream_t compute_stream = nullptr, copy_stream = nullptr;
-	std::vector<hipEvent_t> slice_done;
+	// host-buffer entries: frames in on one stream, kernels on a second, samples out on a third (created on first use)
+	hipStream_t h2d_stream = nullptr, compute_stream = nullptr, copy_stream = nullptr;
+	std::vector<hipEvent_t> slice_done; // two per slice: frames arrived, samples ready
+	int rows5_for(size_t) const { return 1; } // model 5: utterances per workgroup
 };
 
 namespace {
@@ -146,6 +148,9 @@ void free_plan(gvtm_plan* p)
 	p->s_audio.release();
 	p->s_counts.release();
 	p->s_maxabs.release();
+	p->s_pcm.release();
+	p->s_scales.release();
+	if (p->h2d_stream) (void) hipStreamDestroy(p->h2d_stream);
 	if (p->compute_stream) (void) hipStreamDestroy(p->compute_stream);
 	if (p->copy_stream) (void) hipStreamDestroy(p->copy_stream);
 	for (hipEvent_t ev : p->slice_done) (void) hipEventDestroy(ev);
@@ -213,6 +218,7 @@ int gvtm_plan_create(const gvtm_config* config, double control_rate, int device,
 		if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
 			return fail(GVTM_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
 		}
+		plan->compute_units = prop.multiProcessorCount;
 		const gvtm::Design& dg = plan->design;
 		if (dg.f32) {
 			if ((e = upload(&plan->d_wavetable, dg.wavetable_f)) != hipSuccess) return fail_hip(e, "upload wavetable");
@@ -261,6 +267,7 @@ int gvtm_plan_create_model5(const gvtm5_config* config, double control_rate, int
 		if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
 			return fail(GVTM_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
 		}
+		plan->compute_units = prop.multiProcessorCount;
 		const gvtm::Design& dg = plan->design;
 		if ((e = upload(&plan->d_src_h, dg.src_h)) != hipSuccess) return fail_hip(e, "upload src_h");
 		if ((e = upload(&plan->d_src_dh, dg.src_dh)) != hipSuccess) return fail_hip(e, "upload src_dh");
@@ -688,24 +695,50 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	return launch_batch(plan, d_params, d_frame_counts, batch, max_frames, d_audio, audio_stride, d_out_counts, d_maxabs, hip_stream, nullptr);
 }
 
-int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
-		size_t batch, size_t max_frames, float* audio, size_t audio_stride,
-		int64_t* out_counts, float* maxabs)
+} // extern "C"
+
+namespace {
+
+// The host-buffer entries: frames in host memory -> samples in host memory, float32 (unscaled outputBuffer() samples) or
+// int16 (scaled by 0.95 / max|x| and rounded as WAVEFileWriter::writeSample does, Controller.cpp:315-340,
+// WAVEFileWriter.cpp:122-125 -- half the bytes over PCIe, which is what bounds this entry).
+struct HostJob {
+	const float* params;
+	const int32_t* frame_counts;
+	size_t batch, max_frames;
+	float* audio;      // float32 output [batch][stride], or null
+	int16_t* pcm;      // int16 output [batch][stride], or null
+	size_t stride;
+	int64_t* out_counts;
+	float* maxabs;
+	float* scales;     // pcm only: the scale applied to each utterance, or null
+};
+
+// A batch of at least two machine-fulls goes in slices of one machine-full each (rows x compute units utterances: every
+// compute unit busy, in the shape the whole batch would use), three streams deep:
+//     H2D frames(i + 1)  ||  kernel(i) [+ scale -> int16(i)]  ||  D2H samples(i - 1)
+// With page-locked host buffers (gvtm_host_alloc) all three really overlap; with pageable ones the runtime stages the
+// copies itself and the call still returns the same bytes.
+int host_pipeline(gvtm_plan* plan, const HostJob& j)
 {
 	if (!plan) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan");
 	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan (GVTM_DEVICE_NONE): there is no CPU synthesis path");
+	const size_t batch = j.batch, max_frames = j.max_frames, audio_stride = j.stride;
 	if (batch == 0) return GVTM_OK;
-	if (!audio) return fail(GVTM_ERR_INVALID_ARGUMENT, "null audio buffer");
-	if (max_frames > 0 && !params) return fail(GVTM_ERR_INVALID_ARGUMENT, "null params with max_frames > 0");
+	if (!j.audio && !j.pcm) return fail(GVTM_ERR_INVALID_ARGUMENT, "null output buffer");
+	if (max_frames > 0 && !j.params) return fail(GVTM_ERR_INVALID_ARGUMENT, "null params with max_frames > 0");
+	if (audio_stride < gvtm_output_count(plan, max_frames)) {
+		return fail(GVTM_ERR_INVALID_ARGUMENT, "audio_stride smaller than gvtm_output_count(plan, max_frames)");
+	}
 	// A frame count outside [0, max_frames] fails THAT utterance (out_counts[b] = -1, no samples); the others are
 	// synthesized.  The device sees it as an empty utterance.
 	std::vector<int32_t> sane;
 	std::vector<size_t> bad;
 	try {
-		if (frame_counts) {
+		if (j.frame_counts) {
 			for (size_t b = 0; b < batch; ++b) {
-				if (frame_counts[b] < 0 || static_cast<size_t>(frame_counts[b]) > max_frames) {
-					if (sane.empty()) sane.assign(frame_counts, frame_counts + batch);
+				if (j.frame_counts[b] < 0 || static_cast<size_t>(j.frame_counts[b]) > max_frames) {
+					if (sane.empty()) sane.assign(j.frame_counts, j.frame_counts + batch);
 					sane[b] = 0;
 					bad.push_back(b);
 				}
@@ -714,87 +747,153 @@ int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32
 	} catch (const std::bad_alloc&) {
 		return fail(GVTM_ERR_OUT_OF_MEMORY, "host allocation failed");
 	}
-	const int32_t* const counts_in = sane.empty() ? frame_counts : sane.data();
+	const int32_t* const counts_in = sane.empty() ? j.frame_counts : sane.data();
 	DeviceScope scope(plan->device);
 	hipError_t e = scope.status();
 	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-	const size_t pbytes = sizeof(float) * batch * max_frames * GVTM_N_PARAM;
+	const size_t row_in = max_frames * GVTM_N_PARAM;
+	const size_t pbytes = sizeof(float) * batch * row_in;
 	const size_t abytes = sizeof(float) * batch * audio_stride;
+	const size_t obytes = sizeof(int16_t) * batch * audio_stride;
 	if ((e = plan->s_params.ensure(pbytes ? pbytes : 16)) != hipSuccess) return fail_hip(e, "hipMalloc params");
 	if ((e = plan->s_audio.ensure(abytes ? abytes : 16)) != hipSuccess) return fail_hip(e, "hipMalloc audio");
 	if ((e = plan->s_counts.ensure(sizeof(int64_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc counts");
 	if ((e = plan->s_maxabs.ensure(sizeof(float) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc maxabs");
 	if (counts_in && (e = plan->s_frames.ensure(sizeof(int32_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc frames");
-	if (pbytes && (e = hipMemcpy(plan->s_params.ptr, params, pbytes, hipMemcpyHostToDevice)) != hipSuccess) return fail_hip(e, "H2D params");
-	if (counts_in && (e = hipMemcpy(plan->s_frames.ptr, counts_in, sizeof(int32_t) * batch, hipMemcpyHostToDevice)) != hipSuccess) {
-		return fail_hip(e, "H2D frame_counts");
-	}
-	// Large batches go in slices: the kernels of all slices are queued on one stream, and each slice's samples are
-	// copied back on another stream as soon as its kernel has finished, while the following slices still compute
-	// (1.4 GB come back for 4096 x 2 s: the copy takes longer than the kernels).  A slice keeps every compute unit
-	// busy with the shape the whole batch would have used (1024 utterances = 256 workgroups of four).
-	constexpr size_t kSlice = 1024;
+	if (j.pcm && (e = plan->s_pcm.ensure(obytes ? obytes : 16)) != hipSuccess) return fail_hip(e, "hipMalloc pcm");
+	if (j.pcm && (e = plan->s_scales.ensure(sizeof(float) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc scales");
+	if (!plan->h2d_stream && (e = hipStreamCreateWithFlags(&plan->h2d_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
+	if (!plan->compute_stream && (e = hipStreamCreateWithFlags(&plan->compute_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
+	if (!plan->copy_stream && (e = hipStreamCreateWithFlags(&plan->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
+
 	float* const d_params = static_cast<float*>(plan->s_params.ptr);
 	const int32_t* const d_frames = counts_in ? static_cast<const int32_t*>(plan->s_frames.ptr) : nullptr;
 	float* const d_audio = static_cast<float*>(plan->s_audio.ptr);
+	int16_t* const d_pcm = j.pcm ? static_cast<int16_t*>(plan->s_pcm.ptr) : nullptr;
+	float* const d_scales = j.pcm ? static_cast<float*>(plan->s_scales.ptr) : nullptr;
 	int64_t* const d_counts = static_cast<int64_t*>(plan->s_counts.ptr);
 	float* const d_maxabs = static_cast<float*>(plan->s_maxabs.ptr);
-	// rows come back zero beyond their sample count (the staging buffer is reused between calls)
+	if (counts_in && (e = hipMemcpy(plan->s_frames.ptr, counts_in, sizeof(int32_t) * batch, hipMemcpyHostToDevice)) != hipSuccess) {
+		return fail_hip(e, "H2D frame_counts");
+	}
+	// rows come back zero beyond their sample count (the staging buffers are reused between calls)
 	const bool ragged = counts_in != nullptr || audio_stride > gvtm_output_count(plan, max_frames);
-	if (batch >= 2 * kSlice) {
-		if (!plan->compute_stream && (e = hipStreamCreateWithFlags(&plan->compute_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
-		if (!plan->copy_stream && (e = hipStreamCreateWithFlags(&plan->copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail_hip(e, "hipStreamCreate");
-		const size_t n_slices = (batch + kSlice - 1) / kSlice;
-		while (plan->slice_done.size() < n_slices) {
-			hipEvent_t ev = nullptr;
-			if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail_hip(e, "hipEventCreate");
-			plan->slice_done.push_back(ev);
+
+	// the shape of the whole batch, and how many utterances fill the machine once in it
+	const bool model5 = plan->design.model5;
+	const int rows_all = model5 ? plan->rows5_for(batch) : gvtm::synth_rows(plan->precision, batch, plan->rows, plan->design.k.section_delay);
+	const size_t machine = static_cast<size_t>(rows_all) * static_cast<size_t>(plan->compute_units > 0 ? plan->compute_units : 256);
+	const size_t slice = batch >= 2 * machine ? machine : batch;
+	const size_t n_slices = (batch + slice - 1) / slice;
+	while (plan->slice_done.size() < 2 * n_slices) {
+		hipEvent_t ev = nullptr;
+		if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return fail_hip(e, "hipEventCreate");
+		plan->slice_done.push_back(ev);
+	}
+	auto drain = [&]() {
+		(void) hipStreamSynchronize(plan->h2d_stream);
+		(void) hipStreamSynchronize(plan->compute_stream);
+		(void) hipStreamSynchronize(plan->copy_stream);
+	};
+	const int saved_rows = plan->rows;
+	if (!model5 && plan->rows == 0) plan->rows = rows_all; // every slice in the whole batch's shape
+	int rc = GVTM_OK;
+	for (size_t i = 0; i < n_slices && rc == GVTM_OK; ++i) {
+		const size_t lo = i * slice, n = std::min(slice, batch - lo);
+		hipEvent_t in_done = plan->slice_done[2 * i], out_ready = plan->slice_done[2 * i + 1];
+		if (pbytes && (e = hipMemcpyAsync(d_params + lo * row_in, j.params + lo * row_in, sizeof(float) * n * row_in, hipMemcpyHostToDevice,
+				plan->h2d_stream)) != hipSuccess) { rc = fail_hip(e, "H2D params"); break; }
+		if ((e = hipEventRecord(in_done, plan->h2d_stream)) != hipSuccess) { rc = fail_hip(e, "hipEventRecord"); break; }
+		if ((e = hipStreamWaitEvent(plan->compute_stream, in_done, 0)) != hipSuccess) { rc = fail_hip(e, "hipStreamWaitEvent"); break; }
+		if (ragged && !j.pcm && (e = hipMemsetAsync(d_audio + lo * audio_stride, 0, sizeof(float) * n * audio_stride, plan->compute_stream)) != hipSuccess) {
+			rc = fail_hip(e, "hipMemsetAsync"); break;
 		}
-		const int saved_rows = plan->rows;
-		if (plan->rows == 0) plan->rows = gvtm::synth_rows(plan->precision, batch, 0, plan->design.k.section_delay); // the whole batch's shape
-		int rc = GVTM_OK;
-		if (ragged && (e = hipMemsetAsync(d_audio, 0, abytes, plan->compute_stream)) != hipSuccess) rc = fail_hip(e, "hipMemsetAsync");
-		for (size_t i = 0; i < n_slices && rc == GVTM_OK; ++i) {
-			const size_t lo = i * kSlice, n = std::min(kSlice, batch - lo);
-			rc = gvtm_synthesize_batch_device(plan, d_params + lo * max_frames * GVTM_N_PARAM, d_frames ? d_frames + lo : nullptr, n, max_frames,
-					d_audio + lo * audio_stride, audio_stride, d_counts + lo, d_maxabs + lo, plan->compute_stream);
-			if (rc == GVTM_OK && (e = hipEventRecord(plan->slice_done[i], plan->compute_stream)) != hipSuccess) rc = fail_hip(e, "hipEventRecord");
+		if (ragged && j.pcm && (e = hipMemsetAsync(d_pcm + lo * audio_stride, 0, sizeof(int16_t) * n * audio_stride, plan->compute_stream)) != hipSuccess) {
+			rc = fail_hip(e, "hipMemsetAsync"); break;
 		}
-		plan->rows = saved_rows;
-		if (rc != GVTM_OK) {
-			(void) hipStreamSynchronize(plan->compute_stream);
-			return rc;
-		}
-		for (size_t i = 0; i < n_slices; ++i) {
-			const size_t lo = i * kSlice, n = std::min(kSlice, batch - lo);
-			if ((e = hipStreamWaitEvent(plan->copy_stream, plan->slice_done[i], 0)) != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
-			if ((e = hipMemcpyAsync(audio + lo * audio_stride, d_audio + lo * audio_stride, sizeof(float) * n * audio_stride, hipMemcpyDeviceToHost,
-					plan->copy_stream)) != hipSuccess) {
-				return fail_hip(e, "D2H audio");
+		rc = gvtm_synthesize_batch_device(plan, d_params + lo * row_in, d_frames ? d_frames + lo : nullptr, n, max_frames,
+				d_audio + lo * audio_stride, audio_stride, d_counts + lo, d_maxabs + lo, plan->compute_stream);
+		if (rc != GVTM_OK) break;
+		if (j.pcm) {
+			// (normalize takes at most 65535 utterances per launch: a slice is far below that unless the batch is one slice)
+			for (size_t q = 0; q < n && rc == GVTM_OK; q += 32768) {
+				const size_t m = std::min<size_t>(32768, n - q);
+				rc = gvtm_normalize_batch_device(plan, d_audio + (lo + q) * audio_stride, m, audio_stride, d_counts + lo + q, d_maxabs + lo + q, nullptr,
+						d_pcm + (lo + q) * audio_stride, d_scales + lo + q, plan->compute_stream);
 			}
+			if (rc != GVTM_OK) break;
 		}
-		if ((e = hipStreamSynchronize(plan->copy_stream)) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution / D2H audio");
-		if ((e = hipStreamSynchronize(plan->compute_stream)) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
-	} else {
-		if (ragged && (e = hipMemsetAsync(d_audio, 0, abytes, nullptr)) != hipSuccess) return fail_hip(e, "hipMemsetAsync");
-		const int rc = gvtm_synthesize_batch_device(plan, d_params, d_frames, batch, max_frames, d_audio, audio_stride, d_counts, d_maxabs, nullptr);
-		if (rc != GVTM_OK) return rc;
-		if ((e = hipDeviceSynchronize()) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
-		if ((e = hipMemcpy(audio, d_audio, abytes, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H audio");
+		if ((e = hipEventRecord(out_ready, plan->compute_stream)) != hipSuccess) { rc = fail_hip(e, "hipEventRecord"); break; }
 	}
-	if (out_counts && (e = hipMemcpy(out_counts, d_counts, sizeof(int64_t) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
-		return fail_hip(e, "D2H counts");
+	plan->rows = saved_rows;
+	if (rc != GVTM_OK) {
+		drain();
+		return rc;
 	}
-	if (maxabs && (e = hipMemcpy(maxabs, d_maxabs, sizeof(float) * batch, hipMemcpyDeviceToHost)) != hipSuccess) {
-		return fail_hip(e, "D2H maxabs");
+	// (second loop: with pageable host memory a device-to-host copy blocks the calling thread until its slice is done,
+	// so every kernel is queued before the first of them)
+	for (size_t i = 0; i < n_slices; ++i) {
+		const size_t lo = i * slice, n = std::min(slice, batch - lo);
+		if ((e = hipStreamWaitEvent(plan->copy_stream, plan->slice_done[2 * i + 1], 0)) != hipSuccess) { drain(); return fail_hip(e, "hipStreamWaitEvent"); }
+		if (j.pcm) e = hipMemcpyAsync(j.pcm + lo * audio_stride, d_pcm + lo * audio_stride, sizeof(int16_t) * n * audio_stride, hipMemcpyDeviceToHost, plan->copy_stream);
+		else e = hipMemcpyAsync(j.audio + lo * audio_stride, d_audio + lo * audio_stride, sizeof(float) * n * audio_stride, hipMemcpyDeviceToHost, plan->copy_stream);
+		if (e != hipSuccess) { drain(); return fail_hip(e, "D2H samples"); }
 	}
+	if ((e = hipStreamSynchronize(plan->copy_stream)) != hipSuccess) { drain(); return fail_hip(e, "vtm_synth_kernel execution / D2H samples"); }
+	if ((e = hipStreamSynchronize(plan->compute_stream)) != hipSuccess) return fail_hip(e, "vtm_synth_kernel execution");
+	if ((e = hipStreamSynchronize(plan->h2d_stream)) != hipSuccess) return fail_hip(e, "H2D params");
+	// (everything this plan has launched so far is complete: superseded noise tables can go)
+	for (void* q : plan->noise_retired) (void) hipFree(q);
+	plan->noise_retired.clear();
+	if (j.out_counts && (e = hipMemcpy(j.out_counts, d_counts, sizeof(int64_t) * batch, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H counts");
+	if (j.maxabs && (e = hipMemcpy(j.maxabs, d_maxabs, sizeof(float) * batch, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H maxabs");
+	if (j.scales && d_scales && (e = hipMemcpy(j.scales, d_scales, sizeof(float) * batch, hipMemcpyDeviceToHost)) != hipSuccess) return fail_hip(e, "D2H scales");
 	for (size_t b : bad) {
-		if (out_counts) out_counts[b] = -1;
-		if (maxabs) maxabs[b] = 0.0f;
-		std::fill(audio + b * audio_stride, audio + (b + 1) * audio_stride, 0.0f);
+		if (j.out_counts) j.out_counts[b] = -1;
+		if (j.maxabs) j.maxabs[b] = 0.0f;
+		if (j.scales) j.scales[b] = 0.0f;
+		if (j.audio) std::fill(j.audio + b * audio_stride, j.audio + (b + 1) * audio_stride, 0.0f);
+		if (j.pcm) std::fill(j.pcm + b * audio_stride, j.pcm + (b + 1) * audio_stride, int16_t(0));
 	}
 	if (!bad.empty()) g_last_error = "frame_counts entry outside [0, max_frames]: those utterances have out_counts = -1";
 	return GVTM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
+		size_t batch, size_t max_frames, float* audio, size_t audio_stride,
+		int64_t* out_counts, float* maxabs)
+{
+	if (batch != 0 && !audio) return fail(GVTM_ERR_INVALID_ARGUMENT, "null audio buffer");
+	return host_pipeline(plan, HostJob{params, frame_counts, batch, max_frames, audio, nullptr, audio_stride, out_counts, maxabs, nullptr});
+}
+
+int gvtm_synthesize_batch_host_pcm16(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
+		size_t batch, size_t max_frames, int16_t* pcm, size_t pcm_stride,
+		int64_t* out_counts, float* maxabs, float* scales)
+{
+	if (batch != 0 && !pcm) return fail(GVTM_ERR_INVALID_ARGUMENT, "null pcm buffer");
+	return host_pipeline(plan, HostJob{params, frame_counts, batch, max_frames, nullptr, pcm, pcm_stride, out_counts, maxabs, scales});
+}
+
+int gvtm_host_alloc(size_t bytes, void** ptr_out)
+{
+	if (!ptr_out) return fail(GVTM_ERR_INVALID_ARGUMENT, "null ptr_out");
+	*ptr_out = nullptr;
+	if (bytes == 0) return GVTM_OK;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(GVTM_ERR_NO_DEVICE, "no HIP device available: page-locked memory comes from the HIP runtime");
+	const hipError_t e = hipHostMalloc(ptr_out, bytes, hipHostMallocPortable);
+	if (e != hipSuccess) { *ptr_out = nullptr; return e == hipErrorOutOfMemory ? fail(GVTM_ERR_OUT_OF_MEMORY, "hipHostMalloc: out of memory") : fail_hip(e, "hipHostMalloc"); }
+	return GVTM_OK;
+}
+
+void gvtm_host_free(void* ptr)
+{
+	if (ptr) (void) hipHostFree(ptr);
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -28,6 +28,9 @@
  *                               execSynthesisStep() calls (vtm/VocalTractModel0.h:221-252, :396-445), reset() (:309-326)
  *                               and finishSynthesis() (:720-723), so that an utterance can be handed over in pieces
  *                               (long tracks; the editor's interactive polling, InteractiveAudio.cpp:141-185)
+ *   gvtm_synthesize_batch_host_pcm16
+ *                               the path as `gama_tts vtm` ends it: Controller::synthesizeToFile's int16 samples
+ *                               (Controller.cpp:236-252, :325-340; WAVEFileWriter.cpp:122-125)
  *   gvtm_normalize_batch_device Controller::writeOutputToBuffer / writeOutputToFile scaling,
  *                               Util::calculateOutputScale (Controller.cpp:315-340,
  *                               vtm/VTMUtil.cpp:48-67, WAVEFileWriter.cpp:122-125)
@@ -234,6 +237,25 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 int gvtm_synthesize_batch_host(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
 		size_t batch, size_t max_frames, float* audio, size_t audio_stride,
 		int64_t* out_counts, float* maxabs);
+
+/* The same path ending where the reference's file writer ends (Controller::writeOutputToFile, Controller.cpp:325-340 with
+ * WAVEFileWriter::writeSample, WAVEFileWriter.cpp:122-125): pcm[b][i] = round(x[b][i] * (0.95 / max|x[b]|) * 32767) as
+ * int16, exactly the samples `gama_tts vtm` puts into its WAV file -- 2 bytes per sample cross PCIe instead of 4.
+ *   pcm        [batch][pcm_stride] int16, rows zero beyond their sample count
+ *   scales     [batch] the factor 0.95 / max|x| applied to each utterance (0 for silence), may be NULL
+ *   maxabs     [batch] max|x| of the unscaled samples, may be NULL
+ * Both host entries cut a batch of two or more machine-fulls (utterances per workgroup x compute units) into slices and
+ * run   H2D frames(i+1) || kernel(i) [+ scaling(i)] || D2H samples(i-1)   on three streams.  The overlap is real when
+ * the host buffers are page-locked (gvtm_host_alloc, hipHostMalloc, hipHostRegister); pageable buffers give the same
+ * bytes, with the runtime staging the copies. */
+int gvtm_synthesize_batch_host_pcm16(gvtm_plan* plan, const float* params, const int32_t* frame_counts,
+		size_t batch, size_t max_frames, int16_t* pcm, size_t pcm_stride,
+		int64_t* out_counts, float* maxabs, float* scales);
+
+/* Page-locked host memory for the buffers of the host entries (hipHostMalloc, portable across devices), for callers
+ * that do not link the HIP runtime themselves.  gvtm_host_free(NULL) is a no-op. */
+int gvtm_host_alloc(size_t bytes, void** ptr_out);
+void gvtm_host_free(void* ptr);
 
 /* ---------------------------------------------------------------------------------------------
  * Streams: a batch of utterances synthesized piece by piece.

@@ -212,6 +212,42 @@ def test_batched_vtm_cli_against_wavs_the_reference_wrote(name, golden, golden_w
         assert np.count_nonzero(got != want) <= max(2, got.size // 10000)
 
 
+def test_batched_vtm_cli_ragged_batch_with_a_flush_overrun_length(tmp_path):
+    """Two files one frame apart on a down-sampling voice (model 3 at 44.1 kHz): 2334 frames is a length at which the
+    reference's converter runs into its flush overrun (SampleRateConverter.h:298-308 with :462-471; pinned by the
+    reference-made vectors of tests/test_gpu_overrun.py) and yields 411 798 samples, 575 MORE than the 2335-frame
+    neighbour.  The CLI's rows must be sized with gvtm_output_capacity: with the longest utterance's count the first WAV
+    would lose its tail (and read into the next row)."""
+    voice = str(tmp_path / "voice")
+    _make_voice_dir(voice, "3")
+    out_dir = str(tmp_path / "out")
+    os.makedirs(out_dir)
+    import tracks
+    pool = tracks.random_tracks(2, 2335, seed0=2334, consonant_heavy=True)
+    tracks_ = {"overrun2334": pool[0, :2334], "plain2335": pool[1]}
+    files = []
+    for name, tr in tracks_.items():
+        p = str(tmp_path / (name + ".txt"))
+        with open(p, "w") as f:
+            for row in tr:
+                f.write(" ".join("%.9g" % v for v in row) + "\n")
+        files.append(p)
+    r = subprocess.run([CLI, voice, out_dir] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cfg = oracle.male_config(44100.0, 3)
+    sizes = {}
+    for name, tr in tracks_.items():
+        fmt, pcm = _read_wav(os.path.join(out_dir, name + ".wav"))
+        ref = oracle.synthesize(cfg, tr)
+        sizes[name] = pcm.size
+        assert pcm.size == ref.size
+        scaled = (ref * np.float32(oracle.output_scale(ref))) * np.float32(32767.0)
+        want = (np.sign(scaled) * np.floor(np.abs(scaled) + np.float32(0.5))).astype(np.int32)
+        assert np.abs(pcm.astype(np.int32) - want).max() <= 1
+        assert np.count_nonzero(pcm.astype(np.int32) != want) <= max(2, pcm.size // 10000)
+    assert sizes == {"overrun2334": 411798, "plain2335": 411223}
+
+
 def test_batched_cli_shards_across_device_slots(golden, tmp_path):
     """`-d 0,0,0`: three device slots (the same GPU three times on a one-GPU box), seven utterances -> contiguous
     shards of 3, 2, 2, each on its own host thread and plan (BASELINE configs[4] layout, no exchange between

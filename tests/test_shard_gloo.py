@@ -81,3 +81,47 @@ def test_bench_rank_workload_defaults_match_baseline_configs():
     # the other tubes keep the 256 x 2 s workload
     a5 = bench.parse_args(["--model", "5"])
     assert (a5.batch, a5.frames, a5.delay, a5.precision, a5.output_rate) == (256, 500, 1, "f64", 48000.0)
+
+
+def test_launch_plan_is_what_a_launcher_would_export():
+    """`python bench.py --gpus N` without torch.distributed.run: one child per device with the launcher's environment."""
+    plan = bench.launch_plan(4, ["--gpus", "4", "--steps", "3"], 29123)
+    assert len(plan) == 4
+    for r, (cmd, env) in enumerate(plan):
+        assert cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "3"]
+        assert env == {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": "4", "LOCAL_WORLD_SIZE": "4",
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29123"}
+
+
+def _run_bench(argv, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_python_start():
+    """A plain `python bench.py --gpus 2` (no WORLD_SIZE): the parent spawns two fresh rank processes before touching any
+    GPU, they rendezvous on 127.0.0.1 and cut the batch into contiguous shards; ONE line comes back, from rank 0, with
+    n_gpus = 2.  (--rehearse-launch: the launcher, the process group and the rank logic without the GPU work, so that
+    this runs on the CPU-only build box; BASELINE configs[4] = 4096 utterances per GPU.)"""
+    r, line = _run_bench(["--gpus", "2", "--rehearse-launch"])
+    assert r.returncode == 0, r.stderr
+    assert line == {"rehearsal": True, "n_gpus": 2, "global_batch": 8192, "shards": [[0, 4096], [4096, 8192]],
+                    "max_over_ranks_of_1_plus_rank": 2.0, "launcher": "self"}
+    assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1
+
+
+def test_bench_self_launch_with_a_fixed_global_batch_and_a_failing_rank():
+    r, line = _run_bench(["--gpus", "3", "--global-batch", "1000", "--rehearse-launch"])
+    assert r.returncode == 0, r.stderr
+    assert line["n_gpus"] == 3 and line["shards"] == [[0, 334], [334, 667], [667, 1000]]
+    # without GPUs the real (non-rehearsal) ranks fail loudly, and the parent reports it instead of hanging in a barrier
+    import torch
+    if not torch.cuda.is_available():
+        r, line = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+        assert r.returncode != 0 and line is None
+        assert "needs a GPU" in r.stderr
