@@ -32,8 +32,9 @@ _RANGES = np.array([
     (0.1, 1.5)], dtype=np.float64)
 
 
-def random_track(frames, seed, consonant_heavy=False):
-    """Piecewise-linear track between random key-frames every 20-60 frames."""
+def random_track(frames, seed, consonant_heavy=False, unvoiced=0.3):
+    """Piecewise-linear track between random key-frames every 20-60 frames; `unvoiced` = share of key-frames with the
+    glottal volume at 0 (30 %; 0.0 gives a corpus that never takes the kernel's voicing gate)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     keys_t = [0]
     while keys_t[-1] < frames - 1:
@@ -42,8 +43,11 @@ def random_track(frames, seed, consonant_heavy=False):
     nk = len(keys_t)
     u = rng.random((nk, N_PARAM))
     vals = _RANGES[:, 0] + u * (_RANGES[:, 1] - _RANGES[:, 0])
-    unvoiced = rng.random(nk) < 0.3
-    vals[unvoiced, 1] = 0.0
+    silent = rng.random(nk) < 0.3  # (always drawn: the other parameters do not depend on `unvoiced`)
+    if unvoiced >= 0.3:
+        vals[silent, 1] = 0.0
+    elif unvoiced > 0.0:
+        vals[silent & (rng.random(nk) < unvoiced / 0.3), 1] = 0.0
     if consonant_heavy:
         m = rng.random(nk) < 0.5
         vals[m, 15] = 0.5 + rng.random(m.sum()) * 1.0          # velum >= 0.5
@@ -58,8 +62,8 @@ def random_track(frames, seed, consonant_heavy=False):
     return out.astype(np.float32)
 
 
-def random_tracks(batch, frames, seed0=1000, consonant_heavy=False):
-    return np.stack([random_track(frames, seed0 + b, consonant_heavy) for b in range(batch)])
+def random_tracks(batch, frames, seed0=1000, consonant_heavy=False, unvoiced=0.3):
+    return np.stack([random_track(frames, seed0 + b, consonant_heavy, unvoiced) for b in range(batch)])
 
 
 def edge_track(frames=48, seed=0):

@@ -6,7 +6,7 @@ for v in variants:
     env = dict(os.environ)
     if v != "default":
         env["GVTM_LIBRARY"] = os.path.join("gama_tts_amd", "lib_variants", "libgama_vtm_%s.so" % v)
-    r = subprocess.run([sys.executable, "bench.py", "--precision", prec, "--batch", batch, "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras"],
+    r = subprocess.run([sys.executable, "bench.py", "--precision", prec, "--batch", batch, "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--no-end-to-end", "--no-parity-check"],
                        capture_output=True, text=True, env=env)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
