@@ -114,7 +114,12 @@ struct gvtm_plan {
 	// host-buffer entries: frames in on one stream, kernels on a second, samples out on a third (created on first use)
 	hipStream_t h2d_stream = nullptr, compute_stream = nullptr, copy_stream = nullptr;
 	std::vector<hipEvent_t> slice_done; // two per slice: frames arrived, samples ready
-	int rows5_for(size_t) const { return 1; } // model 5: utterances per workgroup
+	// model 5: utterances per workgroup.  One, whatever the batch: the two-utterance shape (two tube wavefronts, chunk of 24
+	// steps -- what LDS holds of the 62-entry tube records) measured SLOWER at every batch size (batch 512 x 250 frames:
+	// 17.3 ms against 2 x 6.97 ms; profiles/r03_role_cycles_m5.txt): the passes are latency-bound, so a chunk of 24 steps
+	// costs what one of 60 does, and the tube wavefronts slow down from 268 to 430 cycles per step next to five busy
+	// helpers.  A diagnostics build can still force it (tests hold it to the one-utterance shape's samples bit for bit).
+	int rows5_for(size_t) const { return rows == 2 ? 2 : 1; }
 };
 
 namespace {
@@ -356,7 +361,7 @@ int gvtm_debug_set_rows(gvtm_plan* plan, int rows)
 size_t gvtm_debug_lds_bytes(const gvtm_plan* plan, int rows)
 {
 	if (!plan) return 0;
-	if (plan->design.model5) return gvtm::synth5_lds_bytes();
+	if (plan->design.model5) return gvtm::synth5_lds_bytes(rows == 2 ? 2 : 1);
 	return gvtm::synth_lds_bytes(plan->design.k, plan->precision, rows, 0);
 }
 
@@ -585,13 +590,13 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 	const bool model5 = plan->design.model5;
 	const gvtm::DeviceConstants& k = plan->design.k;
 	constexpr size_t kLdsPerWorkgroup = 160 * 1024;
-	int rows = model5 ? 1 : gvtm::synth_rows(plan->precision, batch, plan->rows, k.section_delay);
+	int rows = model5 ? plan->rows5_for(batch) : gvtm::synth_rows(plan->precision, batch, plan->rows, k.section_delay);
 	if (sl && sl->rows == 1) rows = 1;
 	const int xr_fixed = sl ? sl->xr : 0;
 	// a shape whose rings do not fit (down-sampling plans carry the reference's 1024-sample ring per row) gives way to
 	// the next smaller one
 	while (!model5 && rows > 1 && gvtm::synth_lds_bytes(k, plan->precision, rows, xr_fixed) > kLdsPerWorkgroup) rows /= 2;
-	if ((model5 ? gvtm::synth5_lds_bytes() : gvtm::synth_lds_bytes(k, plan->precision, rows, xr_fixed)) > kLdsPerWorkgroup) {
+	if ((model5 ? gvtm::synth5_lds_bytes(rows) : gvtm::synth_lds_bytes(k, plan->precision, rows, xr_fixed)) > kLdsPerWorkgroup) {
 		return fail(GVTM_ERR_UNSUPPORTED, "LDS budget exceeded");
 	}
 
@@ -674,7 +679,7 @@ int launch_batch(gvtm_plan* plan, const float* d_params, const int32_t* d_frame_
 		}
 		if ((e = hipEventRecord(ev.start, stream)) != hipSuccess) return fail_hip(e, "hipEventRecord");
 	}
-	e = model5 ? gvtm::launch_synth5(args, batch, stream)
+	e = model5 ? gvtm::launch_synth5(args, batch, rows, stream)
 	           : gvtm::launch_synth(args, batch, plan->precision, rows, stream);
 	if (plan->timing) {
 		(void) hipEventRecord(ev.stop, stream);
@@ -796,7 +801,7 @@ int host_pipeline(gvtm_plan* plan, const HostJob& j)
 		(void) hipStreamSynchronize(plan->copy_stream);
 	};
 	const int saved_rows = plan->rows;
-	if (!model5 && plan->rows == 0) plan->rows = rows_all; // every slice in the whole batch's shape
+	if (plan->rows == 0) plan->rows = rows_all; // every slice in the whole batch's shape
 	int rc = GVTM_OK;
 	for (size_t i = 0; i < n_slices && rc == GVTM_OK; ++i) {
 		const size_t lo = i * slice, n = std::min(slice, batch - lo);

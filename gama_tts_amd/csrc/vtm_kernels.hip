@@ -244,23 +244,37 @@ hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int 
 	return launch_v2_rows<double, double>(args, batch, rows, stream);
 }
 
-// reference model 5: chunk of 60 steps (one 64-lane pass per per-step stage), three helper wavefronts
-constexpr int kM5Chunk = 60, kM5Helpers = 3, kM5Ring = kSrcRing; // the reference's BUFFER_SIZE: see the flush-overrun epilogue
+// reference model 5.  One utterance per workgroup: chunk of 60 steps (one 64-lane pass per per-step stage), three helper
+// wavefronts.  Two utterances per workgroup (batches beyond one workgroup per compute unit): two tube wavefronts, chunk of
+// 24 steps (2 x 24 items per per-step pass; what LDS holds with two 62-entry tube records per step), five helpers.
+constexpr int kM5Ring = kSrcRing; // the reference's BUFFER_SIZE: see the flush-overrun epilogue
+constexpr int kM5Chunk1 = 60, kM5Helpers1 = 3;
+#ifndef GVTM_TUNE_M5_NH2
+#define GVTM_TUNE_M5_NH2 5
+#endif
+constexpr int kM5Chunk2 = 24, kM5Helpers2 = GVTM_TUNE_M5_NH2;
 
-size_t synth5_lds_bytes()
+size_t synth5_lds_bytes(int rows)
 {
-	return m5::Offsets<kM5Chunk, kM5Ring>().total;
+	return rows == 2 ? m5::Offsets<kM5Chunk2, kM5Ring, 2>().total : m5::Offsets<kM5Chunk1, kM5Ring, 1>().total;
 }
 
-hipError_t launch_synth5(const SynthArgs& args, size_t batch, hipStream_t stream)
+template <int C, int NH, int U>
+static hipError_t launch_synth5_shape(const SynthArgs& args, size_t batch, hipStream_t stream)
 {
-	if (!args.k5const) return hipErrorInvalidValue;
-	auto fn = m5::vtm5_synth_kernel<kM5Chunk, kM5Helpers, kM5Ring>;
-	const size_t lds = synth5_lds_bytes();
+	auto fn = m5::vtm5_synth_kernel<C, NH, kM5Ring, U>;
+	const size_t lds = m5::Offsets<C, kM5Ring, U>().total;
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
 	if (e != hipSuccess) return e;
-	hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(batch)), dim3((4 + kM5Helpers) * 64), lds, stream, args);
+	hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>((batch + U - 1) / U)), dim3((3 + U + NH) * 64), lds, stream, args);
 	return hipGetLastError();
+}
+
+hipError_t launch_synth5(const SynthArgs& args, size_t batch, int rows, hipStream_t stream)
+{
+	if (!args.k5const) return hipErrorInvalidValue;
+	if (rows == 2) return launch_synth5_shape<kM5Chunk2, kM5Helpers2, 2>(args, batch, stream);
+	return launch_synth5_shape<kM5Chunk1, kM5Helpers1, 1>(args, batch, stream);
 }
 
 hipError_t launch_normalize(const NormalizeArgs& args, size_t batch, hipStream_t stream)

@@ -94,9 +94,9 @@ hipError_t launch_synth(const SynthArgs& args, size_t batch, int precision, int 
 // bytes of one utterance's stream state for a plan (ring length of the one-row shape: streams whose utterances are not in
 // lockstep run one utterance per workgroup, and every shape of a stream uses that ring length)
 size_t stream_state_bytes(const DeviceConstants& k, int precision, int xr);
-// reference model 5 (VocalTractModel5<double,1>): one utterance per workgroup, fp64
-size_t synth5_lds_bytes();
-hipError_t launch_synth5(const SynthArgs& args, size_t batch, hipStream_t stream);
+// reference model 5 (VocalTractModel5<double,1>), fp64: rows = utterances per workgroup, 1 or 2
+size_t synth5_lds_bytes(int rows = 1);
+hipError_t launch_synth5(const SynthArgs& args, size_t batch, int rows, hipStream_t stream);
 constexpr int kDppSelftestInts = 640;
 hipError_t launch_dpp_selftest(int* d_out /* [kDppSelftestInts] */, hipStream_t stream);
 hipError_t launch_float_math_probe(int kind, const float* d_x, size_t n, float* d_out, hipStream_t stream);

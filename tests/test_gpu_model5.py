@@ -185,3 +185,65 @@ def test_host_entry_slices_large_batches():
     # the pool repeats every 50 utterances, the frame counts every 7: 350 apart the utterances are the same
     valid = np.arange(audio.shape[1])[None, :] < counts[:350, None]
     assert np.array_equal(audio[:350][valid], audio[1050:1400][valid]) and np.array_equal(audio[:350][valid], audio[1750:2100][valid])
+
+
+def _plan_rows(rows, overrides=None, rate=48000.0, crate=250.0):
+    """A diagnostics plan with the utterances per workgroup forced (1: one tube wavefront, chunk 60; 2: two, chunk 24)."""
+    d = g.read_config_file(oracle.VOICE5_MALE)
+    d.update({k: str(v) for k, v in (overrides or {}).items()})
+    return g.Plan(g.config5_from_dict(d, rate), crate, 0, diagnostics=True, rows=rows)
+
+
+@pytest.mark.parametrize("case", DOUBLE_CASES, ids=lambda c: c["name"])
+def test_reference_vectors_two_utterances_per_workgroup(case, golden, golden5):
+    """The reference-made vectors through the two-utterance workgroup shape (vtm5_synth_kernel<24, 5, 1024, 2>: what batches
+    beyond one workgroup per compute unit get), the vector in BOTH slots of a workgroup and beside a different neighbour."""
+    tr = golden5_cases.track_for(case, golden)
+    other = tracks.random_track(tr.shape[0], 77, True)
+    plan = _plan_rows(2, case["overrides"], case["rate"], case["crate"])
+    audio, counts, _ = plan.synthesize_host(np.stack([tr, other, other, tr, tr]))
+    m = golden5["manifest"][case["name"]]
+    bypass = int(case["overrides"].get("bypass", 0)) == 1
+    for b in (0, 3, 4):
+        assert counts[b] == m["n"]
+        out = audio[b, : m["n"]]
+        if case["store"] == "full":
+            _check(out, golden5[case["name"] + "__out"], bypass, m["maxabs"])
+        else:
+            _check(out[:: golden5_cases.DIGEST_STRIDE], golden5[case["name"] + "__strided"], bypass, m["maxabs"])
+    assert np.array_equal(audio[0], audio[3]) and np.array_equal(audio[0], audio[4])
+
+
+def test_two_utterances_per_workgroup_ragged_against_the_one_utterance_shape_and_the_oracle():
+    """Ragged lengths (0, 1, 2 frames, flush-overrun lengths 106 and 353, an odd batch): the two-utterance shape must give the
+    one-utterance shape's samples bit for bit, and both the oracle's."""
+    frames = np.array([40, 0, 1, 106, 2, 40, 17, 106, 33, 5, 40], dtype=np.int32)
+    params = tracks.random_tracks(len(frames), 106, seed0=5150, consonant_heavy=True)
+    a1, c1, m1 = _plan_rows(1).synthesize_host(params, frames)
+    a2, c2, m2 = _plan_rows(2).synthesize_host(params, frames)
+    assert np.array_equal(c1, c2) and np.array_equal(m1, m2)
+    assert np.array_equal(a1, a2)
+    cfg = oracle.male5_config(48000.0)
+    for b in (0, 2, 3, 6, 10):
+        ref, _ = oracle.synthesize5(cfg, params[b, : frames[b]])
+        assert c2[b] == ref.size
+        _check(a2[b, : ref.size], ref)
+
+
+def test_product_library_on_a_batch_beyond_one_workgroup_per_compute_unit():
+    """600 utterances (> 256 compute units) through libgama_vtm.so with nothing forced: a pool of 12 ragged tracks tiled,
+    every pool member against the oracle, every copy equal to its first occurrence."""
+    pool_f = np.array([30, 0, 7, 30, 19, 1, 30, 12, 25, 30, 3, 28], dtype=np.int32)
+    pool = tracks.random_tracks(len(pool_f), 30, seed0=6000, consonant_heavy=True)
+    batch = 601
+    idx = np.arange(batch) % len(pool_f)
+    plan = _plan()
+    audio, counts, maxabs = plan.synthesize_host(pool[idx], pool_f[idx])
+    cfg = oracle.male5_config(48000.0)
+    for t in range(len(pool_f)):
+        ref, _ = oracle.synthesize5(cfg, pool[t, : pool_f[t]])
+        assert counts[t] == ref.size
+        _check(audio[t, : ref.size], ref)
+        assert maxabs[t] == (np.abs(audio[t, : ref.size]).max() if ref.size else 0.0)
+    for b in range(len(pool_f), batch):
+        assert counts[b] == counts[b % len(pool_f)] and np.array_equal(audio[b], audio[b % len(pool_f)]), b
