@@ -932,10 +932,20 @@ unsigned gcd_u(unsigned a, unsigned b)
 int stream_upload_fresh_state(gvtm_stream* s)
 {
 	std::vector<unsigned char> init(s->state_stride * s->batch, 0);
+	const bool model5 = s->plan->design.model5;
 	for (size_t b = 0; b < s->batch; ++b) {
 		gvtm::StreamHeader h{};
 		h.seed = 0.7892347; // NoiseSource::reset (vtm/NoiseSource.h:32-34)
 		std::memcpy(init.data() + b * s->state_stride, &h, sizeof(h));
+		if (model5) {
+			// VocalTractModel5::reset (vtm/VocalTractModel5.h:423-453): RosenbergBGlottalSource::reset leaves t2 at the end of the
+			// longest falling phase, the noise source starts from its seed, everything else is zero
+			const gvtm::Model5Constants& k5 = s->plan->design.k5;
+			double sc[gvtm::kStream5Scalars] = {};
+			sc[gvtm::kS5Scan + 1] = k5.rb_t1 + k5.rb_tn_max;
+			sc[gvtm::kS5Scan + 2] = 0.7892347;
+			std::memcpy(init.data() + b * s->state_stride + gvtm::Stream5Layout::scalars(), sc, sizeof(sc));
+		}
 	}
 	hipError_t e = hipMemcpy(s->d_state.ptr, init.data(), init.size(), hipMemcpyHostToDevice);
 	if (e != hipSuccess) return fail_hip(e, "H2D stream state");
@@ -1037,17 +1047,24 @@ int gvtm_stream_create(gvtm_plan* plan, size_t batch, gvtm_stream** stream_out)
 	if (!plan || !stream_out || batch == 0) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan / stream_out or empty batch");
 	*stream_out = nullptr;
 	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan (GVTM_DEVICE_NONE): there is no CPU synthesis path");
-	if (plan->design.model5) return fail(GVTM_ERR_UNSUPPORTED, "streams are not implemented for reference model 5 plans");
 	try {
 		std::unique_ptr<gvtm_stream> s(new gvtm_stream);
 		s->plan = plan;
 		s->batch = batch;
 		const gvtm::DeviceConstants& k = plan->design.k;
-		s->xr = gvtm::synth_ring_length(k, plan->precision, 1);
-		s->state_stride = gvtm::stream_state_bytes(k, plan->precision, s->xr);
-		// the serial wavefronts work in blocks of 2, 4 and 4 or 6 steps (vtm_kernel_v2.inc): their states are exact at
-		// multiples of 12 steps, so a push synthesizes a multiple of 12 / gcd(control_steps, 12) frames and keeps the rest
-		s->granule_frames = 12u / gcd_u(k.control_steps, 12u);
+		if (plan->design.model5) {
+			// reference model 5: its own state block (vtm_kernels.hpp: Stream5Layout); the serial wavefronts work in blocks
+			// of four steps (vtm_kernel_m5.inc)
+			s->xr = 0;
+			s->state_stride = gvtm::Stream5Layout::bytes();
+			s->granule_frames = 4u / gcd_u(k.control_steps, 4u);
+		} else {
+			s->xr = gvtm::synth_ring_length(k, plan->precision, 1);
+			s->state_stride = gvtm::stream_state_bytes(k, plan->precision, s->xr);
+			// the serial wavefronts work in blocks of 2, 4 and 4 or 6 steps (vtm_kernel_v2.inc): their states are exact at
+			// multiples of 12 steps, so a push synthesizes a multiple of 12 / gcd(control_steps, 12) frames and keeps the rest
+			s->granule_frames = 12u / gcd_u(k.control_steps, 12u);
+		}
 		s->held.resize(batch);
 		s->steps_done.assign(batch, 0);
 		DeviceScope scope(plan->device);

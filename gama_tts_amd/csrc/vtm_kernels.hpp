@@ -42,6 +42,27 @@ struct StreamLayout {
 	static constexpr size_t bytes(int lanes, int words, int xr) { return (ring(lanes, words) + sizeof(ST) * static_cast<size_t>(xr) + 15) & ~size_t(15); }
 };
 
+// Reference model 5 (VocalTractModel5, vtm/VocalTractModel5.h:523-579): what its members keep between steps -- the scans'
+// phases, noise seed and low-pass memories, the recursive filter halves' memories, the last inputs of their feed-forward
+// halves, every section's top / bottom flow and radiation-impedance memories, the converter's 1024-sample ring and the
+// ring of converted samples the difference filter looks back into.  A fresh utterance is zeros except the Rosenberg
+// source's t2 (RosenbergBGlottalSource::reset) and the noise seed.
+constexpr int kS5Scan = 0;     // t, t2, seed, glottal-noise x1 y1, frication-noise x1 x2 y1 y2
+constexpr int kS5Gp = 9;       // glottal low-pass y1
+constexpr int kS5Bp = 10;      // band-pass y1, y2
+constexpr int kS5Fo = 12;      // transmitted flow y1: mouth, nose
+constexpr int kS5ValLast = 14; // last pulse value (the low-pass's x1)
+constexpr int kS5FnmLast = 15; // last two band-pass inputs (x2, x1)
+constexpr int kS5Carry = 17;   // last flow into mouth, nose
+constexpr int kStream5Scalars = 24;
+struct Stream5Layout {
+	static constexpr size_t scalars() { return sizeof(StreamHeader); }
+	static constexpr size_t tube() { return scalars() + sizeof(double) * kStream5Scalars; }
+	static constexpr size_t ring() { return tube() + sizeof(double) * 51 * 4; }
+	static constexpr size_t yring() { return ring() + sizeof(double) * kSrcRing; }
+	static constexpr size_t bytes() { return (yring() + sizeof(float) * 512 + 15) & ~size_t(15); }
+};
+
 struct SynthArgs {
 	DeviceConstants k;              // by value (host-side launch decisions)
 	const DeviceConstants* kconst;  // the same constants in device memory (the kernel stages them in LDS)

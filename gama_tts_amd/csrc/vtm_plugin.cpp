@@ -71,9 +71,6 @@ public:
 		: interactive_(interactive)
 	{
 		const KeyReader k(data);
-		if (interactive && k.has("gpu_model") && k.integer("gpu_model") == 5) {
-			throw std::runtime_error("interactive use of reference model 5 is not served by the device backend (gvtm_stream_create: unsupported)");
-		}
 		const int device = k.has("gpu_device") ? k.integer("gpu_device") : 0;
 		if (k.has("gpu_model") && k.integer("gpu_model") == 5) {
 			// the keys of VocalTractModel5::loadConfiguration (vtm/VocalTractModel5.h:375-421)
@@ -120,6 +117,7 @@ public:
 			if (info.control_steps != 1) throw std::runtime_error("internal error: plugin plan must run one step per frame");
 			current_.assign(GVTM_N_PARAM, 0.0f);
 			output_.reserve(1024);
+			if (interactive_) startInteractive(k);
 			return;
 		}
 		gvtm_config c{};
@@ -169,18 +167,24 @@ public:
 		if (info.control_steps != 1) throw std::runtime_error("internal error: plugin plan must run one step per frame");
 		current_.assign(GVTM_N_PARAM, 0.0f);
 		output_.reserve(1024);
-		if (interactive_) {
-			// steps per launch: the reference's converter hands its samples over every 998 fills; a multiple of 12 near it
-			int block = k.has("gpu_interactive_block") ? k.integer("gpu_interactive_block") : 996;
-			block_steps_ = static_cast<std::size_t>(block < 12 ? 12 : ((block + 11) / 12) * 12);
-			if (gvtm_stream_create(plan_, 1, &stream_) != GVTM_OK) {
-				const std::string why = gvtm_last_error();
-				gvtm_plan_destroy(plan_);
-				plan_ = nullptr;
-				throw std::runtime_error(why);
-			}
-			burst_.resize(gvtm_stream_capacity(stream_, block_steps_));
+		if (interactive_) startInteractive(k);
+	}
+
+	// interactive protocol (is_interactive = true, VocalTractModelPlugin.cpp:87; InteractiveAudio.cpp:141-185): the recorded
+	// steps go to a stream in blocks
+	void startInteractive(const KeyReader& k)
+	{
+		// steps per launch: the reference's converter hands its samples over every 998 fills; a multiple of 12 near it
+		// (12 steps: what the serial wavefronts of every model's kernel are exact at)
+		int block = k.has("gpu_interactive_block") ? k.integer("gpu_interactive_block") : 996;
+		block_steps_ = static_cast<std::size_t>(block < 12 ? 12 : ((block + 11) / 12) * 12);
+		if (gvtm_stream_create(plan_, 1, &stream_) != GVTM_OK) {
+			const std::string why = gvtm_last_error();
+			gvtm_plan_destroy(plan_);
+			plan_ = nullptr;
+			throw std::runtime_error(why);
 		}
+		burst_.resize(gvtm_stream_capacity(stream_, block_steps_));
 	}
 	~DeviceVocalTractModel() noexcept override
 	{

@@ -61,8 +61,8 @@ typedef enum gvtm_status {
 	GVTM_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad size, bad configuration value */
 	GVTM_ERR_NO_DEVICE = 2,        /* no HIP device / device index out of range */
 	GVTM_ERR_HIP = 3,              /* a HIP runtime call failed (see gvtm_last_error) */
-	GVTM_ERR_UNSUPPORTED = 4,      /* valid for the reference but not implemented on the device (e.g. interactive
-	                                  streams of reference model 5) */
+	GVTM_ERR_UNSUPPORTED = 4,      /* valid for the reference but not implemented on the device (e.g. a workgroup shape
+	                                  whose buffers do not fit LDS) */
 	GVTM_ERR_OUT_OF_MEMORY = 5
 } gvtm_status;
 
@@ -275,7 +275,9 @@ void gvtm_host_free(void* ptr);
  *   gvtm_stream_reset   every utterance back to the state after construction (VocalTractModel::reset())
  *
  * Utterances pushed in lockstep (same frame counts every time) share workgroups like a one-shot batch; otherwise a
- * workgroup takes one utterance.  Not implemented for reference model 5 plans (GVTM_ERR_UNSUPPORTED).
+ * workgroup takes one utterance.  Plans of reference model 5 have streams too (vtm/VocalTractModel5.h:523-579: its scans,
+ * filter memories, section flows, radiation-impedance memories, converter ring and the difference filter's look-back are
+ * the state; pushes go in multiples of four internal steps).
  */
 typedef struct gvtm_stream gvtm_stream;
 

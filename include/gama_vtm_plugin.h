@@ -29,8 +29,8 @@
  *     996; the reference's converter itself hands samples over every 998 steps, SampleRateConverter.h:277-281) and the
  *     new samples are appended to outputBuffer() after each block; finishSynthesis() synthesizes what is left and
  *     flushes; reset() starts over.  The sample stream is the batch protocol's, bit for bit
- *     (tests/test_gpu_dropin.py::test_plugin_interactive_protocol_through_reference_loader).  Not served for
- *     `gpu_model = 5` (construct returns NULL).
+ *     (tests/test_gpu_dropin.py::test_plugin_interactive_protocol_through_reference_loader; with `gpu_model = 5`:
+ *     ::test_plugin_model5_interactive_protocol_through_reference_loader).
  *   - No exception crosses the C boundary; any failure inside construct returns NULL and
  *     writes the reason to stderr.
  *   - Optional extra keys in vtm.txt: `gpu_device` (int, default 0), `gpu_precision`

@@ -294,6 +294,31 @@ def test_plugin_model5_through_reference_loader(golden, golden5, tmp_path):
     _check(out, ref)
 
 
+@pytest.mark.skipif(oracle.ref_binary() is None, reason="oracle/_ref/ref_vtm (the compiled reference) not present")
+@pytest.mark.parametrize("poll", [64, 1024])
+def test_plugin_model5_interactive_protocol_through_reference_loader(poll, golden, golden5, tmp_path):
+    """interactive = true with `gpu_model = 5`: the reference's loader constructs the object for the editor's caller contract
+    (VocalTractModelPlugin.cpp:87, InteractiveAudio.cpp:141-185) and polls outputBuffer() after every execSynthesisStep();
+    behind it the steps go to a model-5 stream (VocalTractModel5's state between steps, vtm/VocalTractModel5.h:523-579, kept in
+    device memory).  The drained samples must be the batch protocol's bit for bit, and the reference vector's."""
+    keys = oracle.read_config_file(oracle.VOICE5_MALE)
+    keys["gpu_model"] = "5"
+    cfg = str(tmp_path / "vtm5i.txt")
+    with open(cfg, "w") as f:
+        for k, v in keys.items():
+            f.write("%s = %s\n" % (k, v))
+    import golden5_cases
+    case = next(c for c in golden5_cases.CASES if c["name"] == "rand5_m5")
+    tr = golden5_cases.track_for(case, golden)
+    out, info = oracle.ref_synthesize(tr, "2000:" + PLUGIN, output_rate=48000, config=cfg, tmpdir=str(tmp_path), poll=poll)
+    ref = golden5["rand5_m5__out"]
+    assert out.size == ref.size == int(info["N"]) and int(info["callbacks"]) >= ref.size // poll
+    from test_gpu_model5 import _check
+    _check(out, ref)
+    batch, _ = oracle.ref_synthesize(tr, "2000:" + PLUGIN, output_rate=48000, config=cfg, tmpdir=str(tmp_path))
+    assert np.array_equal(out, batch)
+
+
 def test_batched_vtm_cli_model5_voice(golden, tmp_path):
     """A voice directory whose vtm.txt says `model = 5` (the layout of data/voice/english/5_male): the batched CLI
     writes what `gama_tts vtm` writes for it."""

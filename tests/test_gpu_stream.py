@@ -127,12 +127,65 @@ def test_long_track_in_one_second_pieces():
 
 
 def test_stream_refusals():
-    d = g.read_config_file(oracle.VOICE5_MALE)
-    plan5 = g.Plan(g.config5_from_dict(d), 250.0, 0)
-    with pytest.raises(g.GvtmError) as ei:
-        g.Stream(plan5, 1)
-    assert ei.value.status == 4  # GVTM_ERR_UNSUPPORTED
     none = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE)), 250.0, capi.DEVICE_NONE)
     with pytest.raises(g.GvtmError) as ei:
         g.Stream(none, 1)
     assert ei.value.status == 2  # GVTM_ERR_NO_DEVICE
+
+
+# ---- reference model 5 as a stateful object (vtm/VocalTractModel5.h:523-579) -------------------------------------------
+
+def _plan5(rate=48000.0, crate=250.0, rows=0):
+    d = g.read_config_file(oracle.VOICE5_MALE)
+    return g.Plan(g.config5_from_dict(d, rate), crate, 0, diagnostics=bool(rows), rows=rows)
+
+
+@pytest.mark.parametrize("rate,frames", [(48000.0, 97), (44100.0, 106), (96000.0, 41)], ids=["48k", "44k_overrun106", "96k_up"])
+def test_model5_uneven_blocks_equal_one_shot_bit_for_bit(rate, frames):
+    """Pieces of 1..40 frames (every recurrence, the feed-forward halves' predecessors, the converter's ring and the
+    difference filter's look-back cross launch boundaries at arbitrary places); 106 frames at 44.1 kHz finishes on a flush
+    overrun of the converter."""
+    track = tracks.random_track(frames, 5500, True)
+    plan = _plan5(rate)
+    whole, counts, peak = plan.synthesize_host(track[None])
+    got, maxabs, _ = _stream_one(plan, track, [1, 7, 3, 1, 1, 40, 2, 13, 5, 1, 9])
+    assert got.size == counts[0]
+    assert np.array_equal(got, whole[0, : counts[0]])
+    assert maxabs == peak[0]
+    ref, _ = oracle.synthesize5(oracle.male5_config(rate), track)
+    assert ref.size == got.size
+    assert np.abs(got.astype(np.float64) - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_model5_single_frame_pushes_reset_and_ragged_batch():
+    plan = _plan5()
+    track = tracks.random_track(23, 5600, True)
+    whole, counts, _ = plan.synthesize_host(track[None])
+    got, _, st = _stream_one(plan, track, [1] * 23)
+    assert np.array_equal(got, whole[0, : counts[0]])
+    st.reset()
+    other = tracks.random_track(9, 5601, True)
+    whole2, counts2, _ = plan.synthesize_host(other[None])
+    pieces = st.push(other[None, :4])[0], st.push(other[None, 4:])[0]
+    tail, _ = st.finish()
+    assert np.array_equal(np.concatenate([pieces[0], pieces[1], tail[0]]), whole2[0, : counts2[0]])
+    # a batch stream whose utterances get different numbers of frames per push
+    batch = tracks.random_tracks(3, 30, seed0=5700, consonant_heavy=True)
+    total = np.array([30, 11, 22], dtype=np.int32)
+    one, c1, _ = plan.synthesize_host(batch, total)
+    st3 = g.Stream(plan, 3)
+    outs = [[], [], []]
+    done = np.zeros(3, dtype=np.int32)
+    for n in (5, 9, 16):
+        fc = np.minimum(n, total - done).astype(np.int32)
+        buf = np.zeros((3, n, 16), np.float32)
+        for b in range(3):
+            buf[b, : fc[b]] = batch[b, done[b]: done[b] + fc[b]]
+        res = st3.push(buf, fc)
+        for b in range(3):
+            outs[b].append(res[b])
+        done += fc
+    tails, _ = st3.finish()
+    for b in range(3):
+        whole_b = np.concatenate(outs[b] + [tails[b]])
+        assert whole_b.size == c1[b] and np.array_equal(whole_b, one[b, : c1[b]]), b
