@@ -346,16 +346,22 @@ def end_to_end(g, plan, host_pool, batch, frames, n_timed, kernel_only_rate, lab
     for kind in ("int16", "float32"):
         buf = raw.array.view(np.int16)[: batch * n_out].reshape(batch, n_out) if kind == "int16" else raw.array.reshape(batch, n_out)
         plan.synthesize_host_into(p_in.array, buf, None, counts, None)  # warm-up: staging buffers, streams
+        plan.set_timing(True)
         t0 = time.perf_counter()
         for _ in range(n_timed):
             plan.synthesize_host_into(p_in.array, buf, None, counts, None)
         el = (time.perf_counter() - t0) / n_timed
+        kms, launches = plan.take_kernel_ms()  # the synthesis kernels of these calls (one per slice), HIP events
+        plan.set_timing(False)
+        kernels_ms = kms * launches / n_timed
         assert int(counts.min()) == n_out and int(counts.max()) == n_out
         rate = float(n_out) * batch / el
         out.append({"workload": label, "output": kind, "ms": el * 1e3, "value": rate, "unit": "samples/s",
                     "bytes_over_pcie": float(batch) * (frames * 64.0 + n_out * (2.0 if kind == "int16" else 4.0)),
                     "pcie_gbs": float(batch) * (frames * 64.0 + n_out * (2.0 if kind == "int16" else 4.0)) / el / 1e9,
-                    "vs_kernel_only": rate / kernel_only_rate if kernel_only_rate else None,
+                    "synthesis_kernels_ms": kernels_ms, "slices": launches // n_timed,
+                    "vs_kernel_only": kernels_ms / (el * 1e3),
+                    "kernel_only_value_of_this_workload": kernel_only_rate,
                     "host_buffers": "page-locked (gvtm_host_alloc = hipHostMalloc)"})
     p_in.close()
     raw.close()

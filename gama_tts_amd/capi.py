@@ -157,6 +157,8 @@ def load_library(diagnostics=False):
     L.gvtm_tracks_frame_count.restype = sz
     L.gvtm_generate_tracks_device.argtypes = [i32, ctypes.POINTER(TrackConfig), vp, vp, sz, sz, vp, vp, vp, vp]
     L.gvtm_generate_tracks_device.restype = i32
+    L.gvtm_synthesize_events_device.argtypes = [vp, ctypes.POINTER(TrackConfig), vp, vp, sz, sz, vp, sz, vp, vp, vp, vp, vp]
+    L.gvtm_synthesize_events_device.restype = i32
     L.gvtm_generate_tracks_host.argtypes = [i32, ctypes.POINTER(TrackConfig), vp, vp, sz, sz, vp, vp, vp]
     L.gvtm_generate_tracks_host.restype = i32
     L.gvtm_stream_create.argtypes = [vp, sz, ctypes.POINTER(vp)]
@@ -462,6 +464,13 @@ class Plan:
         scales = np.zeros(batch, dtype=np.float32)
         self.synthesize_host_into(params, pcm, frame_counts, counts, maxabs, scales)
         return pcm, counts, maxabs, scales
+
+    def synthesize_events_device(self, track_config, d_events, d_offsets, batch, max_frames, d_audio, audio_stride,
+                                 d_frame_counts=None, d_out_counts=None, d_maxabs=None, d_drift=None, stream=None):
+        """Event lists in, samples out, one launch (gvtm_synthesize_events_device); all pointers are device memory."""
+        self._check(self._lib.gvtm_synthesize_events_device(
+            self._h, ctypes.byref(track_config), _ptr(d_events), _ptr(d_offsets), int(batch), int(max_frames), _ptr(d_audio),
+            int(audio_stride), _ptr(d_frame_counts), _ptr(d_out_counts), _ptr(d_maxabs), _ptr(d_drift), _ptr(stream)))
 
     def normalize_device(self, d_audio, batch, audio_stride, d_maxabs, d_counts=None, d_out_f32=None, d_out_i16=None,
                          d_scales=None, stream=None):

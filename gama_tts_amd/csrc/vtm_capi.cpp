@@ -700,6 +700,38 @@ int gvtm_synthesize_batch_device(gvtm_plan* plan, const float* d_params, const i
 	return launch_batch(plan, d_params, d_frame_counts, batch, max_frames, d_audio, audio_stride, d_out_counts, d_maxabs, hip_stream, nullptr);
 }
 
+int gvtm_synthesize_events_device(gvtm_plan* plan, const gvtm_track_config* config, const gvtm_event* d_events,
+		const int64_t* d_event_offsets, size_t batch, size_t max_frames, float* d_audio, size_t audio_stride,
+		int32_t* d_frame_counts, int64_t* d_out_counts, float* d_maxabs, gvtm_drift_state* d_drift, void* hip_stream)
+{
+	if (!plan || !config) return fail(GVTM_ERR_INVALID_ARGUMENT, "null plan or config");
+	if (plan->device == GVTM_DEVICE_NONE) return fail(GVTM_ERR_NO_DEVICE, "design-only plan (GVTM_DEVICE_NONE): there is no CPU synthesis path");
+	if (batch == 0) return GVTM_OK;
+	if (!d_events || !d_event_offsets) return fail(GVTM_ERR_INVALID_ARGUMENT, "null events or event_offsets");
+	gvtm::TrackConstants tk{};
+	const char* why = gvtm::design_tracks(*config, tk);
+	if (why[0]) return fail(GVTM_ERR_INVALID_ARGUMENT, why);
+	if (static_cast<double>(tk.control_period) * plan->design.control_rate != 1000.0) {
+		return fail(GVTM_ERR_INVALID_ARGUMENT, "control_period_ms of the track configuration and the plan's control rate disagree");
+	}
+	// Two launches on the caller's stream with a frame buffer of the plan's in between.  (Walking the event lists inside the
+	// synthesis kernel's interpolation wavefront was built and measured: bit-identical, no frame buffer, and 17.2 -> 33.1 ms
+	// per 4096 x 80 events -- an event boundary is a round trip to memory in the middle of a tick, three times over because
+	// the parameter groups run at different lags -- and 125 ms with the next events prefetched into registers, which that
+	// wavefront does not have to spare.  DESIGN.md 6b.)
+	DeviceScope scope(plan->device);
+	hipError_t e = scope.status();
+	if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+	if ((e = plan->s_params.ensure(sizeof(float) * batch * std::max<size_t>(max_frames, 1) * GVTM_N_PARAM)) != hipSuccess) return fail_hip(e, "hipMalloc frames");
+	if ((e = plan->s_frames.ensure(sizeof(int32_t) * batch)) != hipSuccess) return fail_hip(e, "hipMalloc frame counts");
+	int32_t* const counts = d_frame_counts ? d_frame_counts : static_cast<int32_t*>(plan->s_frames.ptr);
+	int rc = gvtm_generate_tracks_device(plan->device, config, d_events, d_event_offsets, batch, max_frames, static_cast<float*>(plan->s_params.ptr), counts,
+			d_drift, hip_stream);
+	if (rc != GVTM_OK) return rc;
+	return launch_batch(plan, static_cast<const float*>(plan->s_params.ptr), counts, batch, max_frames, d_audio, audio_stride, d_out_counts, d_maxabs,
+			hip_stream, nullptr);
+}
+
 } // extern "C"
 
 namespace {

@@ -31,6 +31,9 @@
  *   gvtm_synthesize_batch_host_pcm16
  *                               the path as `gama_tts vtm` ends it: Controller::synthesizeToFile's int16 samples
  *                               (Controller.cpp:236-252, :325-340; WAVEFileWriter.cpp:122-125)
+ *   gvtm_synthesize_events_device
+ *                               EventList::generateOutput (vtm_control_model/EventList.cpp:930-1091) followed by
+ *                               Controller::synthesize in one call: event lists in, samples out
  *   gvtm_normalize_batch_device Controller::writeOutputToBuffer / writeOutputToFile scaling,
  *                               Util::calculateOutputScale (Controller.cpp:315-340,
  *                               vtm/VTMUtil.cpp:48-67, WAVEFileWriter.cpp:122-125)
@@ -361,6 +364,21 @@ size_t gvtm_tracks_frame_count(const gvtm_track_config* config, const gvtm_event
 int gvtm_generate_tracks_device(int device, const gvtm_track_config* config, const gvtm_event* d_events,
 		const int64_t* d_event_offsets, size_t batch, size_t max_frames, float* d_params, int32_t* d_frame_counts,
 		gvtm_drift_state* d_drift, void* hip_stream);
+
+/*
+ * Event lists in, audio out, in one call: gvtm_generate_tracks_device into a frame buffer the plan owns, then
+ * gvtm_synthesize_batch_device, both enqueued on hip_stream (the frames never leave the device and the caller never sees
+ * them).  Works for every plan, reference model 5 included.
+ *   config          its control_period_ms must match the plan's control rate (1000 / control_rate)
+ *   max_frames      frames per utterance the rows are sized for (gvtm_tracks_frame_count on the host); a list that yields
+ *                   more is cut there
+ *   d_frame_counts  [batch] int32 out: frames each list yields, may be NULL
+ *   d_drift         [batch] in/out drift-generator states, or NULL (a fresh generator per utterance)
+ * The remaining arguments are gvtm_synthesize_batch_device's.
+ */
+int gvtm_synthesize_events_device(gvtm_plan* plan, const gvtm_track_config* config, const gvtm_event* d_events,
+		const int64_t* d_event_offsets, size_t batch, size_t max_frames, float* d_audio, size_t audio_stride,
+		int32_t* d_frame_counts, int64_t* d_out_counts, float* d_maxabs, gvtm_drift_state* d_drift, void* hip_stream);
 
 /* Same with host buffers (H2D, kernel, D2H, synchronous). */
 int gvtm_generate_tracks_host(int device, const gvtm_track_config* config, const gvtm_event* events,

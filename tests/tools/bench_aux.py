@@ -73,4 +73,29 @@ for bsz in (256, 4096):
             assert call() == 0
         dt = (time.perf_counter() - t0) / 3
         out["host_entry_%s_batch%d" % (name, bsz)] = {"batch": bsz, "ms": dt * 1e3, "samples_per_s": float(counts.sum()) / dt}
+# --- the same entry with page-locked buffers (gvtm_host_alloc), float32 and int16 output: what the three-stream pipeline gives
+bsz = 4096
+params = g.PinnedArray((bsz, 500, 16), np.float32)
+params.array[...] = np.tile(pool, (bsz // 64, 1, 1))
+for prec, name in ((capi.PRECISION_F32, "f32"), (capi.PRECISION_MIXED, "mixed"), (capi.PRECISION_F64, "f64")):
+    pl = g.Plan(g.config_from_dict(g.read_config_file(oracle.VOICE_MALE), 44100.0, 1, prec), 250.0, 0)
+    n_out = pl.output_count(500)
+    raw = g.PinnedArray((bsz * n_out,), np.float32)
+    counts = np.zeros(bsz, dtype=np.int64)
+    for kind in ("int16", "float32"):
+        buf = raw.array.view(np.int16)[: bsz * n_out].reshape(bsz, n_out) if kind == "int16" else raw.array.reshape(bsz, n_out)
+        pl.synthesize_host_into(params.array, buf, None, counts, None)
+        pl.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pl.synthesize_host_into(params.array, buf, None, counts, None)
+        dt = (time.perf_counter() - t0) / 3
+        kms, launches = pl.take_kernel_ms()
+        pl.set_timing(False)
+        kernels_ms = kms * launches / 3  # all slices of one call
+        out["host_entry_pinned_%s_%s_batch%d" % (name, kind, bsz)] = {
+            "batch": bsz, "ms": dt * 1e3, "samples_per_s": float(counts.sum()) / dt, "synthesis_kernels_ms": kernels_ms,
+            "vs_kernels_only": kernels_ms / (dt * 1e3)}
+    raw.close()
+params.close()
 print(json.dumps(out))
