@@ -84,7 +84,10 @@ struct V2Shape {
 #define GVTM_TUNE_NH_OCTO 6
 #endif
 	// 8 resp. 12 wavefronts per workgroup; eight rows: two wavefronts per serial role + 6 helpers = 16
-	static constexpr int NH = (U_ == 1) ? GVTM_TUNE_NH_SINGLE : (U_ == 8 ? GVTM_TUNE_NH_OCTO : GVTM_TUNE_NH_MULTI);
+#ifndef GVTM_TUNE_NH_F32_4
+#define GVTM_TUNE_NH_F32_4 GVTM_TUNE_NH_MULTI
+#endif
+	static constexpr int NH = (U_ == 1) ? GVTM_TUNE_NH_SINGLE : (U_ == 8 ? GVTM_TUNE_NH_OCTO : ((U_ == 4 && kAllFloat) ? GVTM_TUNE_NH_F32_4 : GVTM_TUNE_NH_MULTI));
 	static constexpr int kWaves = 5 * ((U_ + 3) / 4) + NH;
 };
 
