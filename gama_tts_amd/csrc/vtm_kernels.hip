@@ -83,9 +83,14 @@ struct V2Shape {
 #ifndef GVTM_TUNE_NH_OCTO
 #define GVTM_TUNE_NH_OCTO 6
 #endif
-	// 8 resp. 12 wavefronts per workgroup; eight rows: two wavefronts per serial role + 6 helpers = 16
+	// 8 resp. 12 wavefronts per workgroup (16 in float with four rows, below); eight rows: two wavefronts per serial role + 6 helpers = 16
+	// Float, four utterances per workgroup: ELEVEN helpers = 16 wavefronts, the most a workgroup can have (128 registers
+	// each).  With the tube record in blocks of four steps the tube and pre-tube filter wavefronts need 177 / 150 cycles per
+	// step and the helper pool is the tick: same box, 4096 utterances, SectionDelay 2 x 2000 frames: 7 / 8 / 9 / 11 helpers
+	// -> 107.6 / 106.2 / 103.6 / 100.0 ms; SectionDelay 1 x 500 frames: 14.24 / 14.00 / 13.68 / 13.11 ms.  (Round 2, when
+	// the tube was the tick: 14 / 16 wavefronts 63.0 -> 62.6 ms.  The double models spill at 128 registers: fp64 22.8 -> 24.5 ms.)
 #ifndef GVTM_TUNE_NH_F32_4
-#define GVTM_TUNE_NH_F32_4 GVTM_TUNE_NH_MULTI
+#define GVTM_TUNE_NH_F32_4 11
 #endif
 	static constexpr int NH = (U_ == 1) ? GVTM_TUNE_NH_SINGLE : (U_ == 8 ? GVTM_TUNE_NH_OCTO : ((U_ == 4 && kAllFloat) ? GVTM_TUNE_NH_F32_4 : GVTM_TUNE_NH_MULTI));
 	static constexpr int kWaves = 5 * ((U_ + 3) / 4) + NH;
