@@ -1,19 +1,28 @@
 // EventList::generateOutput on the device (vtm_control_model/EventList.cpp:930-1091).
 //
-// One utterance per wavefront, one lane per parameter (the reference's inner `for j < numParam` loops
-// become 16 lanes; the other 48 stay idle on purpose, see below).  Every lane walks the control periods of its
-// utterance with its own running value + delta (double, as in the reference) and, at an event boundary,
-// its own forward search for the next event that carries a value for its parameter; lane 0 also runs
-// the pitch extras (drift generator, macro-intonation polynomial, mean pitch).  The 16 lanes read one
-// event's parameters[16] (128 contiguous bytes) and write one frame (64 contiguous bytes).
-// The kernel is latency-bound, not throughput-bound: an event boundary is a round trip to memory (~1-2 us)
-// and a wavefront pays it for every boundary of every utterance it hosts, one at a time (the rows diverge).
-// Four utterances per wavefront measured 1.14 ms on batch 4096 x 80 events (13.5 us per event); one per
-// wavefront takes the same boundaries in parallel across four times as many wavefronts.
+// One utterance per workgroup of one wavefront; lanes 0..15 walk (one lane per parameter: the reference's inner
+// `for j < numParam` loops), each with its own running value + delta (double, as in the reference); lane 0 also runs the
+// pitch extras (drift generator, macro-intonation polynomial, mean pitch).
+// The walk is a chain of dependent steps, and in rounds 1 and 2 (0.57 ms per 4096 x 80 events) most of its length was
+// memory round trips at the event boundaries: the reference's forward search for the next event that sets a parameter
+// is a chain of dependent reads (up to a dozen for the sparse special parameters), and on gfx9 loads and stores share one
+// in-order counter (vmcnt), so every boundary also waited for the frames stored before it.  Now:
+//  - a table in LDS says, per event and column, how far ahead the next event that sets the column is (built once per
+//    utterance by lanes 16..47, one per column, from reads that do not depend on each other), so a search is one LDS read
+//    and one read of the event found;
+//  - what a boundary needs (the event just passed, the next event's time, the values found) is requested at the boundary
+//    BEFORE it and looked at a whole inter-event gap later;
+//  - frames collect in LDS and leave 32 at a time as one contiguous 2 KB store by all 64 lanes (one store instruction
+//    in 32 frames' time instead of 32);
+//  - 9.7 KB of LDS and 88 registers: sixteen workgroups per compute unit, a batch of 4096 resident at once.
+// 0.37 ms per 4096 x 80 events.  (Also measured: a separate writer wavefront per utterance, 0.51 ms -- two wavefronts per
+// utterance halve the utterances in flight; the events themselves staged in LDS, 1.29 ms -- 24-32 KB per utterance leave 4-6
+// workgroups per compute unit; four utterances per wavefront, 1.14 ms -- the rows diverge at their boundaries.)
 // Bit parity with the reference: same double operations in the same order, no FMA contraction.
 #include "vtm_tracks.hpp"
 
 #include <cmath>
+#include <cstddef>
 
 namespace gvtm {
 
@@ -24,29 +33,40 @@ __device__ __forceinline__ bool is_empty(double v)
 	return v == HUGE_VAL; // Event::EMPTY_PARAMETER = +infinity (EventList.cpp:38)
 }
 
-// A value that came from memory, re-issued from the vector ALU.  gfx9 counts loads AND stores in one
-// in-order counter (vmcnt): a register the compiler believes may still be in flight at the top of the
-// per-frame loop costs an s_waitcnt vmcnt(0) there, which also waits for the previous frame's STORE to be
-// acknowledged (~2 us per frame, measured 1.19 ms per launch).  Every loop-carried value that is loaded
-// (start values, the next event's time, the intonation cubic) is therefore settled where it is loaded, at an
-// event boundary, and the per-frame path carries ALU results only.
-__device__ __forceinline__ int settle(int v)
-{
-	int r;
-	asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
-	return r;
-}
-__device__ __forceinline__ double settle(double v)
-{
-	return __hiloint2double(settle(__double2hiint(v)), settle(__double2loint(v)));
-}
-
 } // namespace
 
-__global__ __launch_bounds__(16) void vtm_tracks_kernel(const TrackArgs a)
+// column c of an event: parameter c (c < 16) or special parameter c - 16 -- the two arrays follow each other in gvtm_event
+__device__ __forceinline__ double column(const gvtm_event* e, int c)
+{
+	static_assert(offsetof(gvtm_event, special) == offsetof(gvtm_event, param) + 16 * sizeof(double), "param[16] and special[16] are contiguous");
+	return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(e) + offsetof(gvtm_event, param) + sizeof(double) * c);
+}
+
+constexpr int kRingFrames = 32;   // frames collected in LDS before they leave as one 2 KB store
+constexpr int kTableEvents = 240; // event lists up to this length get a "next event that sets column c" table in LDS
+constexpr int kFar = 255;         // table entry: no event within 254 sets the column
+
+// What the boundary at which `target` becomes T looks at, requested one boundary earlier (nothing in the walker wavefront
+// stores to memory, so these loads are waited for exactly where they are used -- a whole inter-event gap later).
+struct Staged {
+	double prev_p, prev_s;        // event T - 1: my parameter / special parameter (set or EMPTY)
+	int prev_has_interp;
+	double i0, i1, i2, i3;        // event T - 1: macro-intonation polynomial
+	int time_t;                   // event T: time
+	double next_p, next_s;        // first event >= T that sets my parameter / special parameter: its value (EMPTY: none) ...
+	int next_p_time, next_s_time; // ... and its time
+};
+
+__global__ __launch_bounds__(64) void vtm_tracks_kernel(const TrackArgs a)
 {
 #pragma clang fp contract(off)
-	const int j = threadIdx.x & 15; // parameter
+	__shared__ __attribute__((aligned(16))) float ring[kRingFrames][16];
+	// ahead[q][c]: how many events after q the first one >= q that sets column c is (0..15 parameters, 16..31 special
+	// parameters); kFar: none within reach.  7.7 KB + the 2 KB above: sixteen workgroups per compute unit, i.e. a batch of
+	// 4096 utterances resident at once.
+	__shared__ unsigned char ahead[kTableEvents + 1][32];
+	const int tid = threadIdx.x;
+	const int j = tid & 15; // parameter (walker lanes 0..15)
 	const size_t utt = blockIdx.x;
 	if (utt >= a.batch) return;
 	const TrackConstants& k = a.k;
@@ -54,13 +74,30 @@ __global__ __launch_bounds__(16) void vtm_tracks_kernel(const TrackArgs a)
 	const int64_t n_events = a.event_offsets[utt + 1] - a.event_offsets[utt];
 	float* out = a.params + utt * a.max_frames * 16;
 	if (n_events < 2) { // EventList.cpp:932-934
-		if (j == 0 && a.frame_counts) a.frame_counts[utt] = 0;
+		if (tid == 0 && a.frame_counts) a.frame_counts[utt] = 0;
 		return;
 	}
+	const bool tabled = n_events <= kTableEvents;
+	// The table: lanes 16..47, one per column, walk the events backwards (the reads do not depend on each other: param[16] and
+	// special[16] are 32 consecutive doubles of an event).
+	if (tabled && tid >= 16 && tid < 48) {
+		const int c = tid - 16;
+		const int ne = static_cast<int>(n_events);
+		int last = ne + kFar; // none so far
+		ahead[ne][c] = kFar;
+#pragma unroll 8
+		for (int q = ne - 1; q >= 0; --q) {
+			if (!is_empty(column(ev + q, c))) last = q;
+			const int d = last - q;
+			ahead[q][c] = static_cast<unsigned char>(d < kFar ? d : kFar);
+		}
+	}
+	// ---- the walk (the whole wavefront runs it: lanes 16..63 mirror lanes 0..15 and never write a frame)
+	const bool walker = tid < 16;
 	const int cp = k.control_period;
 
 	// current values and deltas of my parameter (:944-954); the special parameters start at 0
-	double cur = settle(ev[0].param[j]), delta = 0.0, scur = 0.0, sdelta = 0.0;
+	double cur = ev[0].param[j], delta = 0.0, scur = 0.0, sdelta = 0.0;
 	{
 		int64_t q = 1;
 		double value;
@@ -74,10 +111,7 @@ __global__ __launch_bounds__(16) void vtm_tracks_kernel(const TrackArgs a)
 	double pa = 0.0, pb = 0.0, pc = 0.0, pd = 0.0;
 	gvtm_drift_state ds = {0.7892347, 0.0, 0.0, 0.0, 0.0}; // DriftGenerator.cpp:28, :40
 	if (j == 0) {
-		if (a.drift) {
-			const gvtm_drift_state in = a.drift[utt];
-			ds.seed = settle(in.seed); ds.x1 = settle(in.x1); ds.x2 = settle(in.x2); ds.y1 = settle(in.y1); ds.y2 = settle(in.y2);
-		}
+		if (a.drift) ds = a.drift[utt];
 		if (k.macro_intonation) {
 			int64_t q = 0;
 			for (; q < n_events; ++q) {
@@ -99,9 +133,49 @@ __global__ __launch_bounds__(16) void vtm_tracks_kernel(const TrackArgs a)
 			}
 		}
 	}
+	__syncthreads(); // the table is complete (one wavefront: this orders the LDS writes above before the reads below)
+
+	// first event >= q that sets column c of my lane (c = j: parameter, 16 + j: special), n_events if none; the reference
+	// walks there event by event (:1037-1046, :1055-1064), and so does this for lists too long for the table
+	auto first_set = [&](int64_t q, int c) -> int64_t {
+		if (tabled) {
+			const int d = ahead[q][c];
+			if (d < kFar) return q + d;
+			q += kFar - 1; // nothing in [q, q + 254): on from there
+			if (q >= n_events) return n_events;
+		}
+		while (q < n_events && is_empty(column(ev + q, c))) ++q;
+		return q;
+	};
+	auto stage = [&](int64_t T) { // T <= n_events
+		Staged st;
+		const gvtm_event* pe = ev + (T - 1);
+		st.prev_p = pe->param[j];
+		st.prev_s = pe->special[j];
+		st.prev_has_interp = pe->has_interp;
+		st.i0 = pe->interp[0]; st.i1 = pe->interp[1]; st.i2 = pe->interp[2]; st.i3 = pe->interp[3];
+		const int64_t Tc = T < n_events ? T : n_events - 1;
+		st.time_t = ev[Tc].time_ms;
+		const int64_t qp = first_set(Tc, j), qs = first_set(Tc, 16 + j);
+		st.next_p = HUGE_VAL; st.next_s = HUGE_VAL; st.next_p_time = 0; st.next_s_time = 0;
+		if (qp < n_events) { st.next_p = ev[qp].param[j]; st.next_p_time = ev[qp].time_ms; }
+		if (qs < n_events) { st.next_s = ev[qs].special[j]; st.next_s_time = ev[qs].time_ms; }
+		return st;
+	};
+
+	// the frames [first, end) of the ring leave: 128 float4, two per lane (frames beyond the rows' length are dropped)
+	auto flush = [&](size_t first, size_t end) {
+		if (end > a.max_frames) end = a.max_frames;
+		const float4* src = reinterpret_cast<const float4*>(&ring[0][0]);
+		float4* dst = reinterpret_cast<float4*>(out + first * 16);
+		for (int q = tid; q < kRingFrames * 4; q += 64) {
+			if (first + static_cast<size_t>(q >> 2) < end) dst[q] = src[q];
+		}
+	};
 
 	int64_t target = 1;
-	int target_time = settle(ev[target].time_ms);
+	int target_time = ev[1].time_ms;
+	Staged st = stage(2); // the first boundary makes target 2
 	int now = 0;
 	size_t n = 0;
 	while (target < n_events) { // :988-1086
@@ -127,64 +201,37 @@ __global__ __launch_bounds__(16) void vtm_tracks_kernel(const TrackArgs a)
 			}
 			p += static_cast<float>(k.mean_pitch);
 		}
-		if (n < a.max_frames) out[n * 16 + j] = p;
+		if (walker) ring[n % kRingFrames][j] = p;
 		++n;
+		if (n % kRingFrames == 0) flush(n - kRingFrames, n); // 32 frames x 16 floats = 2 KB contiguous in the output
 
 		if (delta != 0.0) cur += delta;
 		if (sdelta != 0.0) scur += sdelta;
 		now += cp;
 		if (now >= target_time) {
 			if (++target == n_events) break;
-			// The reference walks forward from `target` until it meets an event that sets my parameter: a chain of
-			// dependent reads.  Here the next three events are fetched at once, unconditionally (their addresses
-			// are known), and scanned in registers; only a longer gap falls back to the one-by-one walk.
-			const int64_t q1 = target + 1 < n_events ? target + 1 : n_events - 1;
-			const int64_t q2 = target + 2 < n_events ? target + 2 : n_events - 1;
-			const double prev_p = ev[target - 1].param[j], prev_s = ev[target - 1].special[j];
-			const double p0 = ev[target].param[j], p1 = ev[q1].param[j], p2 = ev[q2].param[j];
-			const double s0 = ev[target].special[j], s1 = ev[q1].special[j], s2 = ev[q2].special[j];
-			const int t0 = ev[target].time_ms, t1 = ev[q1].time_ms, t2 = ev[q2].time_ms;
-			// the event just passed may carry the next macro-intonation polynomial: fetched in the same round trip
-			const int passed_interp = ev[target - 1].has_interp;
-			const double i0 = ev[target - 1].interp[0], i1 = ev[target - 1].interp[1], i2 = ev[target - 1].interp[2],
-					i3 = ev[target - 1].interp[3];
-			target_time = settle(t0);
-			auto next_value = [&](bool special, double v0, double v1, double v2, double& value, int& time) {
-				// first event at or after `target` that sets the parameter; value stays +inf when there is none
-				if (!is_empty(v0)) { value = v0; time = t0; return; }
-				if (!is_empty(v1) || q1 != target + 1) { value = q1 == target + 1 ? v1 : HUGE_VAL; time = t1; return; }
-				if (!is_empty(v2) || q2 != target + 2) { value = q2 == target + 2 ? v2 : HUGE_VAL; time = t2; return; }
-				int64_t q = target + 3;
-				value = HUGE_VAL;
-				while (q < n_events) {
-					value = special ? ev[q].special[j] : ev[q].param[j];
-					if (!is_empty(value)) { time = ev[q].time_ms; return; }
-					++q;
-				}
-			};
-			if (!is_empty(prev_p)) { // :1035-1052
-				double value;
-				int time = 0;
-				next_value(false, p0, p1, p2, value, time);
-				delta = is_empty(value) ? 0.0 : ((value - cur) / (time - now)) * cp;
+			// what the reference finds by walking forward from `target` was requested at the previous boundary
+			const Staged s0 = st;
+			st = stage(target + 1); // for the next boundary
+			target_time = s0.time_t;
+			if (!is_empty(s0.prev_p)) { // :1035-1052
+				delta = is_empty(s0.next_p) ? 0.0 : ((s0.next_p - cur) / (s0.next_p_time - now)) * cp;
 			}
-			if (!is_empty(prev_s)) { // :1053-1070
-				double value;
-				int time = 0;
-				next_value(true, s0, s1, s2, value, time);
-				sdelta = is_empty(value) ? 0.0 : ((value - scur) / (time - now)) * cp;
+			if (!is_empty(s0.prev_s)) { // :1053-1070
+				sdelta = is_empty(s0.next_s) ? 0.0 : ((s0.next_s - scur) / (s0.next_s_time - now)) * cp;
 			}
-			if (j == 0 && k.macro_intonation && passed_interp) { // :1072-1084
-				pa = settle(i0);
-				pb = settle(i1);
+			if (j == 0 && k.macro_intonation && s0.prev_has_interp) { // :1072-1084: the event just passed carries the next polynomial
+				pa = s0.i0;
+				pb = s0.i1;
 				if (k.smooth_intonation) {
-					pc = settle(i2);
-					pd = settle(i3);
+					pc = s0.i2;
+					pd = s0.i3;
 				}
 			}
 		}
 	}
-	if (j == 0) {
+	if (n % kRingFrames != 0) flush(n - n % kRingFrames, n);
+	if (tid == 0) {
 		if (a.frame_counts) a.frame_counts[utt] = static_cast<int32_t>(n);
 		if (a.drift) a.drift[utt] = ds;
 	}
@@ -193,7 +240,7 @@ __global__ __launch_bounds__(16) void vtm_tracks_kernel(const TrackArgs a)
 hipError_t launch_tracks(const TrackArgs& args, hipStream_t stream)
 {
 	if (args.batch == 0) return hipSuccess;
-	hipLaunchKernelGGL(vtm_tracks_kernel, dim3(static_cast<unsigned>(args.batch)), dim3(16), 0, stream, args);
+	hipLaunchKernelGGL(vtm_tracks_kernel, dim3(static_cast<unsigned>(args.batch)), dim3(64), 0, stream, args);
 	return hipGetLastError();
 }
 

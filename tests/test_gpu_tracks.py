@@ -32,7 +32,8 @@ def test_device_matches_captured_reference_calls(name, golden_tracks):
 def test_ragged_batch_against_oracle(flags):
     macro, micro, drift, smooth = flags
     cfg = np.array([4, macro, micro, drift, smooth, -20.0, -6.0, 4.0, 250.0, 4.0])
-    tables = [event_lists.random_event_table(100 + b, n_events=int(n)) for b, n in enumerate([40, 2, 1, 17, 80, 3, 55, 9, 33])]
+    # (110 events is the longest list the kernel stages in LDS; 111, 150 and 260 walk device memory, next to staged neighbours)
+    tables = [event_lists.random_event_table(100 + b, n_events=int(n)) for b, n in enumerate([40, 2, 1, 17, 80, 3, 55, 9, 33, 110, 111, 150, 260])]
     want = [oracle.tracks_generate(oracle.track_config(cfg), t) for t in tables]
     max_frames = max(w[0].shape[0] for w in want)
     params, counts, dr = capi.generate_tracks_host(_product_config(cfg), [capi.events_from_table(t) for t in tables], max_frames,
