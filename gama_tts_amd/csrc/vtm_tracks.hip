@@ -1,8 +1,8 @@
 // EventList::generateOutput on the device (vtm_control_model/EventList.cpp:930-1091).
 //
-// One utterance per workgroup of one wavefront; lanes 0..15 walk (one lane per parameter: the reference's inner
-// `for j < numParam` loops), each with its own running value + delta (double, as in the reference); lane 0 also runs the
-// pitch extras (drift generator, macro-intonation polynomial, mean pitch).
+// Two utterances per workgroup of one wavefront, 32 lanes each; lanes 0..15 of a row walk (one lane per parameter: the
+// reference's inner `for j < numParam` loops), each with its own running value + delta (double, as in the reference); lane 0
+// also runs the pitch extras (drift generator, macro-intonation polynomial, mean pitch).
 // The walk is a chain of dependent steps, and in rounds 1 and 2 (0.57 ms per 4096 x 80 events) most of its length was
 // memory round trips at the event boundaries: the reference's forward search for the next event that sets a parameter
 // is a chain of dependent reads (up to a dozen for the sparse special parameters), and on gfx9 loads and stores share one
@@ -14,8 +14,8 @@
 //    BEFORE it and looked at a whole inter-event gap later;
 //  - frames collect in LDS and leave 32 at a time as one contiguous 2 KB store by all 64 lanes (one store instruction
 //    in 32 frames' time instead of 32);
-//  - 9.7 KB of LDS and 88 registers: sixteen workgroups per compute unit, a batch of 4096 resident at once.
-// 0.37 ms per 4096 x 80 events.  (Also measured: a separate writer wavefront per utterance, 0.51 ms -- two wavefronts per
+//  - 9.7 KB of LDS per utterance and ~90 registers: a batch of 4096 is resident at once.
+// 0.31 ms per 4096 x 80 events (0.37 with one utterance per wavefront).  (Also measured: a separate writer wavefront per utterance, 0.51 ms -- two wavefronts per
 // utterance halve the utterances in flight; the events themselves staged in LDS, 1.29 ms -- 24-32 KB per utterance leave 4-6
 // workgroups per compute unit; four utterances per wavefront, 1.14 ms -- the rows diverge at their boundaries.)
 // Bit parity with the reference: same double operations in the same order, no FMA contraction.
@@ -57,43 +57,39 @@ struct Staged {
 	int next_p_time, next_s_time; // ... and its time
 };
 
-__global__ __launch_bounds__(64) void vtm_tracks_kernel(const TrackArgs a)
+// One utterance, walked by the lanes `l` of its row of the wavefront: lanes 0..15 one parameter each, the rest (if any) mirror
+// them; all of them build the table and carry the frames out.  ring / ahead: the row's LDS.
+template <int LW> // lanes of the row: 64, 32 or 16
+__device__ __forceinline__ void tracks_row(const TrackArgs& a, size_t utt, int l, float (*ring)[16], unsigned char (*ahead)[32])
 {
 #pragma clang fp contract(off)
-	__shared__ __attribute__((aligned(16))) float ring[kRingFrames][16];
-	// ahead[q][c]: how many events after q the first one >= q that sets column c is (0..15 parameters, 16..31 special
-	// parameters); kFar: none within reach.  7.7 KB + the 2 KB above: sixteen workgroups per compute unit, i.e. a batch of
-	// 4096 utterances resident at once.
-	__shared__ unsigned char ahead[kTableEvents + 1][32];
-	const int tid = threadIdx.x;
-	const int j = tid & 15; // parameter (walker lanes 0..15)
-	const size_t utt = blockIdx.x;
-	if (utt >= a.batch) return;
+	const int j = l & 15; // parameter
 	const TrackConstants& k = a.k;
 	const gvtm_event* ev = a.events + a.event_offsets[utt];
 	const int64_t n_events = a.event_offsets[utt + 1] - a.event_offsets[utt];
 	float* out = a.params + utt * a.max_frames * 16;
 	if (n_events < 2) { // EventList.cpp:932-934
-		if (tid == 0 && a.frame_counts) a.frame_counts[utt] = 0;
+		if (l == 0 && a.frame_counts) a.frame_counts[utt] = 0;
 		return;
 	}
 	const bool tabled = n_events <= kTableEvents;
-	// The table: lanes 16..47, one per column, walk the events backwards (the reads do not depend on each other: param[16] and
+	// The table: lanes 0..31, one per column, walk the events backwards (the reads do not depend on each other: param[16] and
 	// special[16] are 32 consecutive doubles of an event).
-	if (tabled && tid >= 16 && tid < 48) {
-		const int c = tid - 16;
+	if (tabled) {
 		const int ne = static_cast<int>(n_events);
-		int last = ne + kFar; // none so far
-		ahead[ne][c] = kFar;
+		for (int c = l; c < 32; c += LW) {
+			int last = ne + kFar; // none so far
+			ahead[ne][c] = kFar;
 #pragma unroll 8
-		for (int q = ne - 1; q >= 0; --q) {
-			if (!is_empty(column(ev + q, c))) last = q;
-			const int d = last - q;
-			ahead[q][c] = static_cast<unsigned char>(d < kFar ? d : kFar);
+			for (int q = ne - 1; q >= 0; --q) {
+				if (!is_empty(column(ev + q, c))) last = q;
+				const int d = last - q;
+				ahead[q][c] = static_cast<unsigned char>(d < kFar ? d : kFar);
+			}
 		}
 	}
-	// ---- the walk (the whole wavefront runs it: lanes 16..63 mirror lanes 0..15 and never write a frame)
-	const bool walker = tid < 16;
+	// ---- the walk (the whole row runs it: lanes 16.. mirror lanes 0..15 and never write a frame)
+	const bool walker = l < 16;
 	const int cp = k.control_period;
 
 	// current values and deltas of my parameter (:944-954); the special parameters start at 0
@@ -133,7 +129,8 @@ __global__ __launch_bounds__(64) void vtm_tracks_kernel(const TrackArgs a)
 			}
 		}
 	}
-	__syncthreads(); // the table is complete (one wavefront: this orders the LDS writes above before the reads below)
+	// the table is complete: one wavefront, whose LDS operations execute in order -- the compiler only has to keep them so
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
 	// first event >= q that sets column c of my lane (c = j: parameter, 16 + j: special), n_events if none; the reference
 	// walks there event by event (:1037-1046, :1055-1064), and so does this for lists too long for the table
@@ -163,12 +160,12 @@ __global__ __launch_bounds__(64) void vtm_tracks_kernel(const TrackArgs a)
 		return st;
 	};
 
-	// the frames [first, end) of the ring leave: 128 float4, two per lane (frames beyond the rows' length are dropped)
+	// the frames [first, end) of the ring leave: 128 float4 over the row's lanes (frames beyond the rows' length are dropped)
 	auto flush = [&](size_t first, size_t end) {
 		if (end > a.max_frames) end = a.max_frames;
 		const float4* src = reinterpret_cast<const float4*>(&ring[0][0]);
 		float4* dst = reinterpret_cast<float4*>(out + first * 16);
-		for (int q = tid; q < kRingFrames * 4; q += 64) {
+		for (int q = l; q < kRingFrames * 4; q += LW) {
 			if (first + static_cast<size_t>(q >> 2) < end) dst[q] = src[q];
 		}
 	};
@@ -231,16 +228,37 @@ __global__ __launch_bounds__(64) void vtm_tracks_kernel(const TrackArgs a)
 		}
 	}
 	if (n % kRingFrames != 0) flush(n - n % kRingFrames, n);
-	if (tid == 0) {
+	if (l == 0) {
 		if (a.frame_counts) a.frame_counts[utt] = static_cast<int32_t>(n);
 		if (a.drift) a.drift[utt] = ds;
 	}
 }
 
+// ROWS utterances per workgroup of one wavefront (64 / ROWS lanes each)
+template <int ROWS>
+__global__ __launch_bounds__(64) void vtm_tracks_kernel(const TrackArgs a)
+{
+	__shared__ __attribute__((aligned(16))) float ring[ROWS][kRingFrames][16];
+	// ahead[q][c]: how many events after q the first one >= q that sets column c is (0..15 parameters, 16..31 special
+	// parameters); kFar: none within reach.  7.7 KB + the 2 KB above per utterance.
+	__shared__ unsigned char ahead[ROWS][kTableEvents + 1][32];
+	const int tid = threadIdx.x;
+	const int row = tid / (64 / ROWS), l = tid % (64 / ROWS);
+	const size_t utt = static_cast<size_t>(blockIdx.x) * ROWS + row;
+	if (utt < a.batch) tracks_row<64 / ROWS>(a, utt, l, ring[row], ahead[row]);
+}
+
 hipError_t launch_tracks(const TrackArgs& args, hipStream_t stream)
 {
 	if (args.batch == 0) return hipSuccess;
-	hipLaunchKernelGGL(vtm_tracks_kernel, dim3(static_cast<unsigned>(args.batch)), dim3(64), 0, stream, args);
+	// Utterances per wavefront.  Two: the per-frame instructions serve two utterances (the walk fills 16 lanes, the wavefront
+	// has 64), a boundary's instructions run when either row is at one; half the wavefronts in flight (19.4 KB of LDS per
+	// workgroup: eight per compute unit).  4096 x 80 events: one / two / four rows 0.37-0.40 / 0.31 / 0.33 ms.
+#ifndef GVTM_TRACK_ROWS
+#define GVTM_TRACK_ROWS 2
+#endif
+	constexpr int kRows = GVTM_TRACK_ROWS;
+	hipLaunchKernelGGL(vtm_tracks_kernel<kRows>, dim3(static_cast<unsigned>((args.batch + kRows - 1) / kRows)), dim3(64), 0, stream, args);
 	return hipGetLastError();
 }
 
